@@ -1,0 +1,143 @@
+/*
+ * lrl_trace.h — C ABI of liblrltrace.so, the MI355X (gfx950) implementation of the per-pixel
+ * ray-tracing path of LRLVEC/RayTracing.  It replaces exactly the device side of one frame of
+ * the reference (all citations relative to /root/reference):
+ *
+ *   reference call site                                   replaced by
+ *   ----------------------------------------------------  ---------------------------------
+ *   model.dataInit()                BVH/BVH.cpp:722        lrl_scene_upload
+ *   TrianglePre / CirclePre         BVH/BVH.cpp:159-168    (inside lrl_scene_upload / _update_triangles)
+ *   triangles re-upload each frame  Pool/Pool.cpp:654-655  lrl_scene_update_triangles
+ *   frameSizeUniform / transUniform BVH/BVH.cpp:718-720,   lrl_set_camera
+ *     .dataInit()/.refreshData()        730,736
+ *   decayOriginStorage.dataInit()   BVH/BVH.cpp:721        lrl_set_decay_origin
+ *   decayOriginCalc.run()           BVH/BVH.cpp:130-138    lrl_compute_decay_origin
+ *   renderer.use(); renderer.run()  BVH/BVH.cpp:741-742    lrl_render
+ *     -> glDrawArrays(TRIANGLE_FAN) BVH/BVH.cpp:42
+ *   glFinish()                      BVH/BVH.cpp:815        lrl_render is synchronous (lrl_render_async + lrl_sync otherwise)
+ *
+ * Conventions: plain pointers and sizes; caller owns every host array (borrowed for the call);
+ * the library owns device memory; every function returns an int status (LRL_OK == 0), never throws.
+ * One host thread per context; one context per GPU.
+ * Output image: RGBA float32, W*H*4, row 0 = bottom row (gl_FragCoord convention), unclamped.
+ */
+#ifndef LRL_TRACE_H
+#define LRL_TRACE_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#include "lrl_types.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct LrlContext LrlContext;
+
+enum LrlStatus {
+    LRL_OK = 0,
+    LRL_ERR_INVALID_ARG = 1,   /* null pointer, zero size, index out of range, malformed BVH */
+    LRL_ERR_DEVICE = 2,        /* HIP runtime error; text via lrl_last_error */
+    LRL_ERR_NO_SCENE = 3,      /* render before scene upload / camera set */
+    LRL_ERR_BVH_DEPTH = 4,     /* BVH deeper than LRL_MAX_BVH_DEPTH */
+    LRL_ERR_OUT_OF_MEMORY = 5,
+    LRL_ERR_LIMIT = 6          /* a stated static limit exceeded (depth, spp, scratch) */
+};
+
+#define LRL_MAX_RAY_DEPTH 10u   /* RayTraceDepth, BVH/shaders/RendererFragment0.cpp:2 (Pool: 8) */
+#define LRL_MAX_BVH_DEPTH 96u   /* traversal stack entries per lane the kernels can be launched with */
+#define LRL_MAX_SPP 4096u
+
+/* Shader variant: the Pool copy of the fragment shader lacks the tex == -2 checkerboard
+ * (diff of Pool/shaders/RendererFragment0.cpp vs BVH/shaders/RendererFragment0.cpp:648-649,713-714). */
+#define LRL_VARIANT_BVH 0u
+#define LRL_VARIANT_POOL 1u
+
+/* Arithmetic mode.  PARITY keeps the reference's operation order (per-node IEEE divides in the slab
+ * test, no fused multiply-add); FAST hoists reciprocals and lets the compiler contract. */
+#define LRL_MODE_PARITY 0u
+#define LRL_MODE_FAST 1u
+
+#define LRL_FLAG_COUNTERS 1u      /* accumulate LrlCounters for this render (slower kernel) */
+#define LRL_FLAG_OUT_DEVICE 2u    /* rgba_out / hit_out are device pointers */
+
+typedef struct LrlSceneView {
+    /* geometry in the reference's record layouts; counts in `num` */
+    LrlGeometryNum        num;
+    const LrlTriangle*    trianglesOrigin;   /* origin form (TrianglePre runs on the device) ...            */
+    const LrlTriangleGPU* trianglesGPU;      /* ... or already in GPU form; exactly one may be non-NULL     */
+    const LrlSphere*      spheres;
+    const LrlCircle*      circles;           /* un-normalised, CirclePre runs on the device                 */
+    const LrlCylinder*    cylinders;
+    const LrlCone*        cones;
+    const LrlPointLight*  pointLights;
+    const LrlBVHNode*     bvh;               /* pre-order array produced by the CPU builder                 */
+    uint32_t              bvhNodeNum;
+    /* textures: BMP payload convention, BGR8, rows bottom-up */
+    uint32_t              texWidth, texHeight, texLayers;
+    const uint8_t*        texBGR;            /* texLayers * texHeight * texWidth * 3, may be NULL           */
+    uint32_t              cubeSize;          /* 0 = no cube map (miss colour 0)                             */
+    const uint8_t*        cubeBGR[6];        /* +X,-X,+Y,-Y,+Z,-Z                                           */
+} LrlSceneView;
+
+typedef struct LrlRenderParams {
+    uint32_t     maxDepth;       /* RayTraceDepth: 10 (BVH), 8 (Pool), 4 (headline config); 1..LRL_MAX_RAY_DEPTH */
+    uint32_t     variant;        /* LRL_VARIANT_*                                                            */
+    uint32_t     mode;           /* LRL_MODE_*                                                               */
+    uint32_t     flags;          /* LRL_FLAG_*                                                               */
+    uint32_t     spp;            /* >= 1; image = mean over samples, summed in sample order                  */
+    const float* jitter;         /* spp*2 sub-pixel offsets (pixels), NULL = pixel centres; applied as the   */
+                                 /* shear of `trans` described in SURVEY §8d                                 */
+    uint32_t     rowBegin, rowEnd; /* render rows [rowBegin,rowEnd); 0,0 = whole frame (multi-GPU stripes)   */
+    uint32_t     sampleBegin, sampleEnd; /* samples [begin,end) of the jitter table; 0,0 = all; the output   */
+                                 /* is then the SUM over that range divided by spp (partial means add up)    */
+} LrlRenderParams;
+
+typedef struct LrlCounters {
+    uint64_t raysPrimary, raysReflect, raysRefract, raysShadow;
+    uint64_t nodeVisits;         /* box tests (one per node visit, closest-hit + any-hit traversals)         */
+    uint64_t triTests, sphereTests, otherTests;
+    uint64_t primaryHits;
+} LrlCounters;
+
+/* ---- life cycle ---- */
+int lrl_create(int device, LrlContext** out);
+int lrl_destroy(LrlContext* ctx);
+const char* lrl_last_error(const LrlContext* ctx);   /* never NULL */
+int lrl_version(void);
+
+/* ---- scene (model.dataInit) ---- */
+int lrl_scene_upload(LrlContext* ctx, const LrlSceneView* scene);
+/* Pool: water triangles rewritten every frame; re-runs TrianglePre on [first, first+count). */
+int lrl_scene_update_triangles(LrlContext* ctx, uint32_t first, uint32_t count, const LrlTriangle* tris);
+/* read back device results of the pre-compute kernels (tests / debugging) */
+int lrl_scene_read_triangles_gpu(LrlContext* ctx, uint32_t first, uint32_t count, LrlTriangleGPU* out);
+int lrl_scene_read_circles(LrlContext* ctx, uint32_t first, uint32_t count, LrlCircle* out);
+
+/* ---- per-frame state ---- */
+int lrl_set_camera(LrlContext* ctx, const LrlTrans* trans, uint32_t width, uint32_t height);
+int lrl_set_decay_origin(LrlContext* ctx, const float decayOrigin[4]);
+/* runs DecayOriginPre (8 probe rays) + DecayOrigin (mode vote) on the device for the current camera;
+ * `variant` selects the BVH (sin-hash directions) or Pool (+z) probe; result stored and optionally returned */
+int lrl_compute_decay_origin(LrlContext* ctx, uint32_t variant, LrlDecayOrigin* out /* may be NULL */);
+
+/* ---- the frame (renderer.run) ---- */
+int lrl_render(LrlContext* ctx, const LrlRenderParams* params,
+               float* rgba_out /* W*(rowEnd-rowBegin)*4 floats */,
+               uint32_t* hit_out /* optional: per pixel {type, index} of the primary hit, 0 = miss */);
+int lrl_render_async(LrlContext* ctx, const LrlRenderParams* params, float* rgba_out_dev, uint32_t* hit_out_dev,
+                     void* hip_stream);
+int lrl_sync(LrlContext* ctx);
+
+/* ---- measurement ---- */
+int lrl_get_counters(LrlContext* ctx, LrlCounters* out);   /* of the last render with LRL_FLAG_COUNTERS */
+/* duration of the trace kernel(s) of the last render, HIP events on the stream they ran on */
+int lrl_last_kernel_ms(LrlContext* ctx, float* ms);
+/* device memory held for the scene (bytes), by class: nodes, triangle hot, triangle cold, other */
+int lrl_scene_device_bytes(LrlContext* ctx, uint64_t out[4]);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* LRL_TRACE_H */

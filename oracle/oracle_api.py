@@ -1,0 +1,111 @@
+"""TEST INFRASTRUCTURE — ctypes front end of oracle/liboracle.so (the CPU restatement) and a runner
+for oracle/_ref/gl_harness (the reference's own GLSL on llvmpipe).  Only tests/, smoke() and
+bench.py's cpu_baseline leg import this module; nothing under raytracing_amd/ does.
+"""
+import ctypes as C
+import json
+import os
+import subprocess
+import tempfile
+
+import numpy as np
+
+from raytracing_amd import abi
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "liboracle.so")
+HARNESS = os.path.join(_HERE, "_ref", "gl_harness")
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise RuntimeError(f"{LIB_PATH} missing: run `make -C oracle` or __graft_entry__.build()")
+        _lib = C.CDLL(LIB_PATH)
+    return _lib
+
+
+def render(view, trans, width, height, max_depth=10, variant=abi.VARIANT_BVH, decay_origin=(0, 0, 0, 1), rows=None, threads=1,
+           want_hits=True):
+    """-> (rgba [rows, W, 4] float32, hits [rows, W, 2] uint32 or None, abi.Counters)"""
+    trans = np.ascontiguousarray(trans, dtype=abi.TRANS).reshape(-1)
+    r0, r1 = rows if rows else (0, height)
+    p = abi.OracleParams(width, height, max_depth, variant, trans.shape[0], r0, r1, threads, (C.c_float * 4)(*decay_origin))
+    img = np.zeros((r1 - r0, width, 4), dtype=np.float32)
+    hits = np.zeros((r1 - r0, width, 2), dtype=np.uint32) if want_hits else None
+    cn = abi.Counters()
+    rc = lib().oracle_render(C.byref(view), trans.ctypes.data_as(C.c_void_p), C.byref(p), img.ctypes.data_as(C.c_void_p),
+                             hits.ctypes.data_as(C.c_void_p) if want_hits else None, C.byref(cn))
+    if rc != 0:
+        raise RuntimeError(f"oracle_render failed ({rc})")
+    return img, hits, cn
+
+
+def triangle_pre(tris):
+    tris = np.ascontiguousarray(tris, dtype=abi.TRIANGLE)
+    out = np.zeros(tris.shape[0], dtype=abi.TRIANGLE_GPU)
+    lib().oracle_triangle_pre(tris.ctypes.data_as(C.c_void_p), C.c_uint32(tris.shape[0]), out.ctypes.data_as(C.c_void_p))
+    return out
+
+
+def circle_pre(circles):
+    out = np.ascontiguousarray(circles, dtype=abi.CIRCLE).copy()
+    lib().oracle_circle_pre(out.ctypes.data_as(C.c_void_p), C.c_uint32(out.shape[0]))
+    return out
+
+
+def decay_origin(view, trans, variant=abi.VARIANT_BVH):
+    trans = np.ascontiguousarray(trans, dtype=abi.TRANS).reshape(-1)
+    out = np.zeros(1, dtype=abi.DECAY_ORIGIN)
+    lib().oracle_decay_origin(C.byref(view), trans.ctypes.data_as(C.c_void_p), C.c_uint32(variant), out.ctypes.data_as(C.c_void_p))
+    return out[0]
+
+
+# ---- the reference itself, on llvmpipe -----------------------------------------------------------
+def harness_available(shader_dir):
+    return os.path.exists(HARNESS) and os.path.isdir(shader_dir) and os.path.exists("/usr/lib/x86_64-linux-gnu/dri/swrast_dri.so")
+
+
+def run_reference(host_model, trans, width, height, shader_dir, max_depth=None, ids=True, min_linear=True, decay=None,
+                  decay_compute=False, want_pre=False, threads=None):
+    """Render `host_model` (raytracing_amd.host.HostModel, after data_init) with the reference's GLSL
+    from `shader_dir`.  -> dict(img, ids, t, tri, circles, decay, timing)"""
+    trans = np.ascontiguousarray(trans, dtype=abi.TRANS).reshape(-1)
+    with tempfile.TemporaryDirectory() as td:
+        scene = os.path.join(td, "scene.lrls")
+        host_model.scene_dump(scene)
+        tf = os.path.join(td, "trans.bin")
+        trans.tofile(tf)
+        cmd = [HARNESS, "render", "--shaders", shader_dir, "--scene", scene, "--trans", tf, "--size", str(width), str(height),
+               "--out", os.path.join(td, "img.bin"), "--decay-out", os.path.join(td, "decay.bin")]
+        if max_depth is not None:
+            cmd += ["--depth", str(max_depth)]
+        if ids:
+            cmd += ["--ids", os.path.join(td, "ids.bin")]
+        if min_linear:
+            cmd += ["--min-linear"]
+        if decay is not None:
+            cmd += ["--decay"] + [repr(float(x)) for x in decay]
+        if decay_compute:
+            cmd += ["--decay-compute"]
+        if want_pre:
+            cmd += ["--tri-out", os.path.join(td, "tri.bin"), "--circle-out", os.path.join(td, "circle.bin")]
+        env = dict(os.environ)
+        if threads:
+            env["LP_NUM_THREADS"] = str(threads)
+        r = subprocess.run(cmd, capture_output=True, text=True, env=env)
+        if r.returncode != 0:
+            raise RuntimeError("gl_harness failed:\n" + r.stderr[-4000:])
+        out = {"timing": json.loads(r.stdout.strip().splitlines()[-1]), "log": r.stderr}
+        out["img"] = np.fromfile(os.path.join(td, "img.bin"), dtype=np.float32).reshape(height, width, 4)
+        if ids:
+            raw = np.fromfile(os.path.join(td, "ids.bin"), dtype=np.uint32).reshape(height, width, 4)
+            out["ids"] = raw[..., :2].copy()
+            out["t"] = raw[..., 2].copy().view(np.float32)
+        out["decay"] = np.fromfile(os.path.join(td, "decay.bin"), dtype=abi.DECAY_ORIGIN)[0]
+        if want_pre:
+            out["tri"] = np.fromfile(os.path.join(td, "tri.bin"), dtype=abi.TRIANGLE_GPU)
+            out["circles"] = np.fromfile(os.path.join(td, "circle.bin"), dtype=abi.CIRCLE)
+        return out

@@ -1,0 +1,165 @@
+// Scene fixtures: the reference demos' hard-coded scenes as functions over lrl::Model.
+//   bvhDefault : the BVH demo scene, numbers from BVH/BVH.cpp:245,280-703 (94 triangles from 11 STL
+//                files, 5 spheres, 1 + 10 + 5 circles, 5 cylinders, 5 cones, 3 lights), camera (0,0,30).
+//   pool       : the Pool demo, Pool/Pool.cpp:465,484,499-606 + initModel :240-299 + water initial
+//                condition :97-112 scattered into the water triangles as WaterPositionSync does
+//                (Pool/shaders/WaterPositionSyncCompute0.cpp:49-74), which the reference runs once at
+//                init (Pool/Pool.cpp:649-650).
+//   mesh       : SURVEY §8d config C2 — one STL mesh (n levels of 1->4 subdivision), mirror-ish
+//                material, ground disc, one light, camera framing the bounding box.  No counterpart
+//                in the reference's apps (RenderSTL is a rasteriser); numbers fixed here.
+// The materials are written through small constructors instead of the reference's 10-field brace
+// lists; values are the reference's.
+#pragma once
+#include <string>
+
+#include "RayTracing.hpp"
+
+namespace lrl {
+namespace scenes {
+
+using Color = Model::Color;
+
+inline Color material(vec3f r, vec3f t, vec3f d, vec3f g, vec3f decay, float n) {
+    Color c{};
+    c.r = r; c.texR = -1; c.t = t; c.texT = -1; c.d = d; c.texD = -1; c.g = g; c.texG = -1;
+    c.decayFactor = decay; c.n = n;
+    return c;
+}
+inline Color glass(vec3f decay, double n) { return material(1, 1, 0, 0, decay, float(n)); }
+inline Color mirror() { return material(0.7, 0, 0, 0, 0, 1); }
+inline Color matte() { return material(0, 0, 1, 0, 0, 1); }
+
+struct Camera {
+    double fovy = 60.0;
+    Math::vec3<double> r0{0, 0, 30};
+    Math::mat3<double> trans = Math::mat3<double>::id();
+    LrlTrans toTrans(unsigned height) const {
+        Transform t({{fovy}, {0.09, 0.9, 0.01}, {0.15}, r0, 700.0});
+        t.trans = trans;
+        FrameScale fs; fs.w = 0; fs.h = int(height);
+        t.init(fs);
+        return t.bufferData.data;
+    }
+};
+
+// resdir = directory holding box/, three/, mirror.stl and (optionally) room/ — BVH/resources of the reference
+inline Camera bvhDefault(Model& m, std::string const& resdir, bool loadCube = true) {
+    auto stl = [&](char const* rel) { return STL::readSTL(resdir + "/" + rel); };
+    {
+        Model::Circles::Circle ground{};
+        ground.plane = {0, 0, 1, 0}; ground.sphere = {0, 0, 0}; ground.r2 = 5000; ground.e1 = {1, 0, 0};
+        ground.color = material(0, 0, 1, 0.1, 0, 1);
+        ground.color.texD = -2;                                         // checkerboard
+        m.circles.data.circles.pushBack(ground);
+    }
+    {
+        struct S { double x, r2; Color c; };
+        const S spheres[5] = {
+            {0, 16, glass({-0.15, -0.15, 0}, 1.5)},
+            {0, 16 * 0.95 * 0.95, glass({0.15, 0.15, 0}, 1 / 1.5)},   // air bubble inside the first
+            {10, 16, mirror()},
+            {20, 16, matte()},
+            {30, 16, glass({-0.15, -0.15, 0}, 1.5)},
+        };
+        for (S const& s : spheres) {
+            Model::Spheres::Sphere sp{};
+            sp.sphere = {s.x, 0, 10, s.r2}; sp.e1 = {0, 0, 1, 0}; sp.e2 = {1, 0, 0, 0}; sp.color = s.c;
+            m.spheres.data.spheres.pushBack(sp);
+        }
+    }
+    m.pointLights.data.pointLights += {
+        {{4000, 4000, 4000}, {0, 0, 300}},
+        {{10, 10, 10}, {-10, 20, 20}},
+        {{10, 10, 10}, {30, 20, 20}},
+    };
+    auto add = [&](char const* rel, Color const& c) { STL s = stl(rel); m.addSTL(s, c, s.triangles.length); };
+    add("box/box1.stl", glass({0, 0, -0.03}, 1.5));
+    add("box/box2.stl", mirror());
+    add("box/box3.stl", matte());
+    add("box/boxtransparent1.stl", glass({0, 0, -0.03}, 1.5));
+    add("box/boxtransparent2.stl", glass({0, 0, 0.03}, 1.0 / 1.5));
+    add("mirror.stl", mirror());
+    {
+        struct C { double y, z, r2, l; Color c; };
+        const C cyl[5] = {
+            {35, 1, 1, 2, glass({0, 0, -0.1}, 1.5)},
+            {37.5, 1, 1, 2, mirror()},
+            {32.5, 1, 1, 2, matte()},
+            {30, 1, 1, 2, glass({0, 0, -0.01}, 1.5)},
+            {30, 1.1, 1 * 0.95 * 0.95, 1.9, glass({0, 0, 0.01}, 1 / 1.5)},
+        };
+        for (C const& c : cyl) {
+            Model::Cylinders::Cylinder k{};
+            k.c = {-15, c.y, c.z}; k.r2 = float(c.r2); k.n = {0, 0, 1}; k.l = float(c.l); k.e1 = {1, 0, 0}; k.color = c.c;
+            m.addCylinder(k);
+        }
+        struct K { double y, z, l2; Color c; };
+        const K cone[5] = {
+            {35, 7, 4, glass({-0.2, 0, -0.2}, 1.5)},
+            {37, 7, 4, mirror()},
+            {33, 7, 4, matte()},
+            {31, 7, 4, glass({-0.2, 0, -0.2}, 1.5)},
+            {31, 7 - 0.1, 4 - 0.5, glass({0.2, 0, 0.2}, 1 / 1.5)},
+        };
+        for (K const& c : cone) {
+            Model::Cones::Cone k{};
+            k.c = {-7, c.y, c.z}; k.c2 = 0.8f; k.n = {0, 0, -1}; k.l2 = float(c.l2); k.e1 = {1, 0, 0}; k.color = c.c;
+            m.addCone(k);
+        }
+    }
+    add("three/three1.stl", glass({0, 0, -0.03}, 1.5));
+    add("three/three2.stl", mirror());
+    add("three/three3.stl", matte());
+    add("three/three transparent1.stl", glass({0, 0, -0.1}, 1.3));
+    add("three/three transparent2.stl", glass({0, 0, 0.1}, 1.0 / 1.3));
+    if (loadCube) m.setCube(BMPCubeData(resdir + "/room/"));
+    m.planes.numChanged = m.triangles.numChanged = m.spheres.numChanged = m.circles.numChanged = true;
+    m.cylinders.numChanged = m.cones.numChanged = m.pointLights.numChanged = true;
+    return Camera{};
+}
+
+// C2: a single STL mesh on a ground disc.  The mesh is lifted so its lowest point rests on z = 0.
+inline Camera mesh(Model& m, STL const& in, unsigned subdivisions) {
+    STL s = in;
+    for (unsigned i = 0; i < subdivisions; ++i) s = s.subdivided();
+    float mn[3] = {FLT_MAX, FLT_MAX, FLT_MAX}, mx[3] = {-FLT_MAX, -FLT_MAX, -FLT_MAX};
+    for (unsigned i = 0; i < s.triangles.length; ++i)
+        for (int v = 0; v < 3; ++v)
+            for (int k = 0; k < 3; ++k) {
+                mn[k] = std::min(mn[k], s.triangles[i].vertices[v][k]);
+                mx[k] = std::max(mx[k], s.triangles[i].vertices[v][k]);
+            }
+    float lift = -mn[2];
+    for (unsigned i = 0; i < s.triangles.length; ++i)
+        for (int v = 0; v < 3; ++v) s.triangles[i].vertices[v][2] += lift;
+    mx[2] += lift; mn[2] = 0;
+    Color body = material(0.7, 0, 1, 0, 0, 1);                 // mirror-ish + diffuse so that 4 bounces occur
+    m.addSTL(s, body, s.triangles.length);
+    double cx = 0.5 * (mn[0] + mx[0]), cy = 0.5 * (mn[1] + mx[1]), cz = 0.5 * mx[2];
+    double ext = std::max({double(mx[0] - mn[0]), double(mx[1] - mn[1]), double(mx[2])});
+    {
+        Model::Circles::Circle ground{};
+        ground.plane = {0, 0, 1, 0}; ground.sphere = {cx, cy, 0}; ground.r2 = float(25 * ext * ext); ground.e1 = {1, 0, 0};
+        ground.color = material(0.3, 0, 1, 0.05, 0, 1);
+        ground.color.texD = -2;
+        m.circles.data.circles.pushBack(ground);
+    }
+    double lp = 2.5 * ext;
+    m.pointLights.data.pointLights += {{{lp * lp * 0.05, lp * lp * 0.05, lp * lp * 0.05}, {cx + 0.6 * lp, cy - 0.5 * lp, lp}}};
+    // camera: on the -y side, slightly above, looking at the bbox centre; camera looks down its -z
+    Camera cam;
+    cam.fovy = 60;
+    Math::vec3<double> target(cx, cy, cz), eye(cx + 0.35 * ext, cy - 1.55 * ext, cz + 0.55 * ext);
+    Math::vec3<double> f = target - eye;                       // forward
+    double fl = std::sqrt(f.dot(f)); f = f * (1 / fl);
+    Math::vec3<double> up(0, 0, 1);
+    Math::vec3<double> r = f.cross(up); r = r * (1 / std::sqrt(r.dot(r)));
+    Math::vec3<double> u = r.cross(f);
+    for (int i = 0; i < 3; ++i) { cam.trans.data[i][0] = r[i]; cam.trans.data[i][1] = u[i]; cam.trans.data[i][2] = -f[i]; }
+    cam.r0 = eye;
+    return cam;
+}
+
+}  // namespace scenes
+}  // namespace lrl
