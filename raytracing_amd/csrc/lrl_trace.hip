@@ -1,0 +1,538 @@
+// liblrltrace.so — implementation of the C ABI declared in include/lrl_trace.h.
+// Host side only: validation, the AoS -> device-layout repack, uploads, launches, timing.
+// The kernels live in kernels_parity.hip / kernels_fast.hip (lrl_kernels.inc).
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cstring>
+#include <string>
+#include <unordered_map>
+#include <vector>
+
+#include "lrl_device.h"
+
+namespace {
+
+struct DevBuf {
+    void* p = nullptr;
+    size_t bytes = 0;
+};
+
+struct ColorKey {
+    uint32_t w[20];
+    bool operator==(ColorKey const& o) const { return std::memcmp(w, o.w, sizeof(w)) == 0; }
+};
+struct ColorHash {
+    size_t operator()(ColorKey const& k) const {
+        uint64_t h = 1469598103934665603ull;
+        for (uint32_t v : k.w) { h ^= v; h *= 1099511628211ull; }
+        return size_t(h);
+    }
+};
+
+}  // namespace
+
+struct LrlContext {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    hipEvent_t evStart = nullptr, evStop = nullptr;
+    std::string err;
+
+    // scene
+    bool haveScene = false, haveCamera = false;
+    LrlGeometryNum num{};
+    uint32_t nodeNum = 0, bvhDepth = 0;
+    DevBuf nodes, triHot, triCold, materials, spheres, circles, cylinders, cones, lights, tex, cube, triStage, matStage;
+    uint32_t texW = 0, texH = 0, texL = 0, cubeSize = 0;
+    std::vector<LrlColor> materialTable;
+    std::unordered_map<ColorKey, uint32_t, ColorHash> materialIndex;
+
+    // frame
+    LrlTrans trans{};
+    uint32_t width = 0, height = 0;
+    float decayOrigin[4] = {0, 0, 0, 1};
+    DevBuf transDev, outDev, hitDev, counterDev, decayDev;
+    float lastMs = 0;
+    bool timed = false;
+    LrlCounters counters{};
+};
+
+namespace {
+
+int fail(LrlContext* c, int code, std::string const& msg) {
+    if (c) c->err = msg;
+    return code;
+}
+#define HIP_TRY(c, expr)                                                                      \
+    do {                                                                                      \
+        hipError_t e_ = (expr);                                                               \
+        if (e_ != hipSuccess) return fail(c, e_ == hipErrorOutOfMemory ? LRL_ERR_OUT_OF_MEMORY : LRL_ERR_DEVICE, \
+                                          std::string(#expr) + ": " + hipGetErrorString(e_)); \
+    } while (0)
+
+int ensure(LrlContext* c, DevBuf& b, size_t bytes) {
+    if (bytes <= b.bytes && b.p) return LRL_OK;
+    if (b.p) { HIP_TRY(c, hipFree(b.p)); b.p = nullptr; b.bytes = 0; }
+    size_t want = std::max<size_t>(bytes, 256);
+    HIP_TRY(c, hipMalloc(&b.p, want));
+    b.bytes = want;
+    return LRL_OK;
+}
+int upload(LrlContext* c, DevBuf& b, const void* src, size_t bytes) {
+    int rc = ensure(c, b, bytes);
+    if (rc) return rc;
+    if (bytes) HIP_TRY(c, hipMemcpyAsync(b.p, src, bytes, hipMemcpyHostToDevice, c->stream));
+    return LRL_OK;
+}
+void release(DevBuf& b) { if (b.p) { (void)hipFree(b.p); b.p = nullptr; b.bytes = 0; } }
+
+uint32_t internMaterial(LrlContext* c, const LrlColor& col) {
+    ColorKey k;
+    std::memcpy(k.w, &col, sizeof(k.w));
+    auto it = c->materialIndex.find(k);
+    if (it != c->materialIndex.end()) return it->second;
+    uint32_t id = uint32_t(c->materialTable.size());
+    c->materialTable.push_back(col);
+    c->materialIndex.emplace(k, id);
+    return id;
+}
+
+// Structural checks of the caller's BVH so that no lane can index outside a buffer or overrun its stack.
+int validateBVH(LrlContext* c, const LrlSceneView* s, uint32_t& depthOut) {
+    const uint32_t N = s->bvhNodeNum;
+    if (N == 0 || N > LRL_NODE_RIGHT_MASK) return fail(c, LRL_ERR_INVALID_ARG, "bvhNodeNum out of range");
+    const uint32_t counts[7] = {0, 0, s->num.triangleNum, s->num.sphereNum, s->num.circleNum, s->num.cylinderNum, s->num.coneNum};
+    for (uint32_t i = 0; i < N; ++i) {
+        const LrlBVHNode& n = s->bvh[i];
+        if (n.bound.leftChild != 0 && i + 1 >= N) return fail(c, LRL_ERR_INVALID_ARG, "BVH: left child past the end");
+        if (n.bound.rightChild != 0 && (n.bound.rightChild < 0 || uint32_t(n.bound.rightChild) >= N || uint32_t(n.bound.rightChild) <= i))
+            return fail(c, LRL_ERR_INVALID_ARG, "BVH: right child index invalid (must be a later pre-order index)");
+        if (n.bound.rightChild != 0 && n.bound.leftChild == 0) return fail(c, LRL_ERR_INVALID_ARG, "BVH: right child without left child");
+        if (n.axis > 2) return fail(c, LRL_ERR_INVALID_ARG, "BVH: axis > 2");
+        if (n.geometry != 0) {
+            if (n.geometry < 2 || n.geometry > 6) return fail(c, LRL_ERR_INVALID_ARG, "BVH: unknown geometry type");
+            if (n.geometryNum >= counts[n.geometry] || n.geometryNum > LRL_NODE_NUM_MASK)
+                return fail(c, LRL_ERR_INVALID_ARG, "BVH: geometryNum out of range");
+        }
+    }
+    // depth by an explicit-stack walk; children always have larger indices, so this terminates
+    std::vector<std::pair<uint32_t, uint32_t>> st;
+    st.emplace_back(0u, 0u);
+    uint32_t depth = 0;
+    size_t visited = 0;
+    while (!st.empty()) {
+        auto [i, d] = st.back();
+        st.pop_back();
+        depth = std::max(depth, d);
+        if (++visited > size_t(N)) return fail(c, LRL_ERR_INVALID_ARG, "BVH: a node is reachable twice");
+        const LrlBVHNode& n = s->bvh[i];
+        if (n.bound.rightChild) st.emplace_back(uint32_t(n.bound.rightChild), d + 1);
+        if (n.bound.leftChild) st.emplace_back(i + 1, d + 1);
+    }
+    depthOut = depth;
+    if (depth + 1 > LRL_MAX_BVH_DEPTH) return fail(c, LRL_ERR_BVH_DEPTH, "BVH deeper than LRL_MAX_BVH_DEPTH");
+    return LRL_OK;
+}
+
+void fillKScene(const LrlContext* c, KScene& k) {
+    k.nodes = static_cast<const float4*>(c->nodes.p);
+    k.triHot = static_cast<const float4*>(c->triHot.p);
+    k.triCold = static_cast<const LrlTriCold*>(c->triCold.p);
+    k.materials = static_cast<const LrlColor*>(c->materials.p);
+    k.spheres = static_cast<const LrlSphere*>(c->spheres.p);
+    k.circles = static_cast<const LrlCircle*>(c->circles.p);
+    k.cylinders = static_cast<const LrlCylinder*>(c->cylinders.p);
+    k.cones = static_cast<const LrlCone*>(c->cones.p);
+    k.lights = static_cast<const LrlPointLight*>(c->lights.p);
+    k.tex = static_cast<const uchar4*>(c->tex.p);
+    k.cube = static_cast<const uchar4*>(c->cube.p);
+    k.lightNum = c->num.pointLightNum;
+    k.texW = c->texW; k.texH = c->texH; k.texL = c->texL;
+    k.cubeSize = c->cubeSize;
+    std::memcpy(k.decayOrigin, c->decayOrigin, 16);
+}
+
+std::vector<uchar4> bgrToRgbx(const uint8_t* bgr, size_t texels) {
+    std::vector<uchar4> o(texels);
+    for (size_t i = 0; i < texels; ++i) o[i] = make_uchar4(bgr[i * 3 + 2], bgr[i * 3 + 1], bgr[i * 3 + 0], 255);
+    return o;
+}
+
+// TrianglePre for [first, first+count): materials interned on the host, geometry on the device.
+int runTrianglePre(LrlContext* c, uint32_t first, uint32_t count, const LrlTriangle* tris) {
+    if (!count) return LRL_OK;
+    std::vector<uint32_t> mat(count);
+    size_t before = c->materialTable.size();
+    for (uint32_t i = 0; i < count; ++i) mat[i] = internMaterial(c, tris[i].color);
+    if (c->materialTable.size() != before || !c->materials.p) {
+        int rc = upload(c, c->materials, c->materialTable.data(), c->materialTable.size() * sizeof(LrlColor));
+        if (rc) return rc;
+    }
+    int rc = upload(c, c->triStage, tris, size_t(count) * sizeof(LrlTriangle));
+    if (rc) return rc;
+    rc = upload(c, c->matStage, mat.data(), size_t(count) * 4);
+    if (rc) return rc;
+    HIP_TRY(c, lrl_launch_triangle_pre(static_cast<const LrlTriangle*>(c->triStage.p), static_cast<const uint32_t*>(c->matStage.p), first,
+                                       count, static_cast<float4*>(c->triHot.p), static_cast<LrlTriCold*>(c->triCold.p), c->stream));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));   // `mat` and the caller's array are borrowed only for this call
+    return LRL_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int lrl_version(void) { return 1; }
+
+const char* lrl_last_error(const LrlContext* ctx) { return ctx ? ctx->err.c_str() : "null context"; }
+
+int lrl_create(int device, LrlContext** out) {
+    if (!out) return LRL_ERR_INVALID_ARG;
+    *out = nullptr;
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess || n <= 0) return LRL_ERR_DEVICE;
+    if (device < 0 || device >= n) return LRL_ERR_INVALID_ARG;
+    LrlContext* c = new (std::nothrow) LrlContext();
+    if (!c) return LRL_ERR_OUT_OF_MEMORY;
+    c->device = device;
+    if (hipSetDevice(device) != hipSuccess || hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess ||
+        hipEventCreate(&c->evStart) != hipSuccess || hipEventCreate(&c->evStop) != hipSuccess) {
+        delete c;
+        return LRL_ERR_DEVICE;
+    }
+    *out = c;
+    return LRL_OK;
+}
+
+int lrl_destroy(LrlContext* c) {
+    if (!c) return LRL_ERR_INVALID_ARG;
+    (void)hipSetDevice(c->device);
+    (void)hipStreamSynchronize(c->stream);
+    for (DevBuf* b : {&c->nodes, &c->triHot, &c->triCold, &c->materials, &c->spheres, &c->circles, &c->cylinders, &c->cones, &c->lights,
+                      &c->tex, &c->cube, &c->triStage, &c->matStage, &c->transDev, &c->outDev, &c->hitDev, &c->counterDev, &c->decayDev})
+        release(*b);
+    if (c->evStart) (void)hipEventDestroy(c->evStart);
+    if (c->evStop) (void)hipEventDestroy(c->evStop);
+    if (c->stream) (void)hipStreamDestroy(c->stream);
+    delete c;
+    return LRL_OK;
+}
+
+int lrl_scene_upload(LrlContext* c, const LrlSceneView* s) {
+    if (!c || !s) return LRL_ERR_INVALID_ARG;
+    HIP_TRY(c, hipSetDevice(c->device));
+    const LrlGeometryNum& g = s->num;
+    if (g.triangleNum && !s->trianglesOrigin == !s->trianglesGPU)
+        return fail(c, LRL_ERR_INVALID_ARG, "exactly one of trianglesOrigin / trianglesGPU must be given");
+    if ((g.sphereNum && !s->spheres) || (g.circleNum && !s->circles) || (g.cylinderNum && !s->cylinders) || (g.coneNum && !s->cones) ||
+        (g.pointLightNum && !s->pointLights) || !s->bvh)
+        return fail(c, LRL_ERR_INVALID_ARG, "null array with non-zero count");
+    if (g.triangleNum > LRL_NODE_NUM_MASK) return fail(c, LRL_ERR_LIMIT, "more than 2^28 triangles");
+    if (s->texLayers && (!s->texBGR || !s->texWidth || !s->texHeight)) return fail(c, LRL_ERR_INVALID_ARG, "texture array incomplete");
+    if (s->cubeSize) for (int i = 0; i < 6; ++i) if (!s->cubeBGR[i]) return fail(c, LRL_ERR_INVALID_ARG, "cube face missing");
+    uint32_t depth = 0;
+    int rc = validateBVH(c, s, depth);
+    if (rc) return rc;
+    c->haveScene = false;
+
+    // nodes: 64-B reference records -> 32-B traversal records
+    {
+        std::vector<float4> packed(size_t(s->bvhNodeNum) * 2);
+        for (uint32_t i = 0; i < s->bvhNodeNum; ++i) {
+            const LrlBVHNode& n = s->bvh[i];
+            uint32_t wa = (uint32_t(n.bound.rightChild) & LRL_NODE_RIGHT_MASK) | (n.axis << LRL_NODE_AXIS_SHIFT);
+            uint32_t wb = (n.geometryNum & LRL_NODE_NUM_MASK) | (n.bound.leftChild ? LRL_NODE_LEFT_BIT : 0u) | (n.geometry << LRL_NODE_GEOM_SHIFT);
+            float fa, fb;
+            std::memcpy(&fa, &wa, 4); std::memcpy(&fb, &wb, 4);
+            packed[size_t(i) * 2] = make_float4(n.bound.min[0], n.bound.min[1], n.bound.min[2], fa);
+            packed[size_t(i) * 2 + 1] = make_float4(n.bound.max[0], n.bound.max[1], n.bound.max[2], fb);
+        }
+        rc = upload(c, c->nodes, packed.data(), packed.size() * sizeof(float4));
+        if (rc) return rc;
+        HIP_TRY(c, hipStreamSynchronize(c->stream));
+    }
+    c->materialTable.clear();
+    c->materialIndex.clear();
+    rc = ensure(c, c->triHot, size_t(g.triangleNum) * 64);
+    if (rc) return rc;
+    rc = ensure(c, c->triCold, size_t(g.triangleNum) * sizeof(LrlTriCold));
+    if (rc) return rc;
+    rc = ensure(c, c->materials, sizeof(LrlColor));
+    if (rc) return rc;
+    c->num = g;
+    if (g.triangleNum) {
+        if (s->trianglesOrigin) {
+            // in slabs, so the staging buffer stays modest for very large meshes
+            const uint32_t slab = 1u << 22;
+            for (uint32_t first = 0; first < g.triangleNum; first += slab) {
+                rc = runTrianglePre(c, first, std::min(slab, g.triangleNum - first), s->trianglesOrigin + first);
+                if (rc) return rc;
+            }
+        } else {
+            std::vector<float4> hot(size_t(g.triangleNum) * 4);
+            std::vector<LrlTriCold> cold(g.triangleNum);
+            for (uint32_t i = 0; i < g.triangleNum; ++i) {
+                const LrlTriangleGPU& t = s->trianglesGPU[i];
+                hot[size_t(i) * 4 + 0] = make_float4(t.plane[0], t.plane[1], t.plane[2], t.plane[3]);
+                hot[size_t(i) * 4 + 1] = make_float4(t.p1[0], t.p1[1], t.p1[2], t.k1[0]);
+                hot[size_t(i) * 4 + 2] = make_float4(t.k1[1], t.k1[2], t.k2[0], t.k2[1]);
+                hot[size_t(i) * 4 + 3] = make_float4(t.k2[2], 0, 0, 0);
+                LrlTriCold& q = cold[i];
+                std::memcpy(q.uv1, t.uv1, 8); std::memcpy(q.uv2, t.uv2, 8); std::memcpy(q.uv3, t.uv3, 8);
+                q.material = internMaterial(c, t.color); q._pad = 0;
+            }
+            rc = upload(c, c->triHot, hot.data(), hot.size() * sizeof(float4));
+            if (rc) return rc;
+            rc = upload(c, c->triCold, cold.data(), cold.size() * sizeof(LrlTriCold));
+            if (rc) return rc;
+            rc = upload(c, c->materials, c->materialTable.data(), c->materialTable.size() * sizeof(LrlColor));
+            if (rc) return rc;
+            HIP_TRY(c, hipStreamSynchronize(c->stream));
+        }
+    }
+    if ((rc = upload(c, c->spheres, s->spheres, size_t(g.sphereNum) * sizeof(LrlSphere)))) return rc;
+    if ((rc = upload(c, c->circles, s->circles, size_t(g.circleNum) * sizeof(LrlCircle)))) return rc;
+    if ((rc = upload(c, c->cylinders, s->cylinders, size_t(g.cylinderNum) * sizeof(LrlCylinder)))) return rc;
+    if ((rc = upload(c, c->cones, s->cones, size_t(g.coneNum) * sizeof(LrlCone)))) return rc;
+    if ((rc = upload(c, c->lights, s->pointLights, size_t(g.pointLightNum) * sizeof(LrlPointLight)))) return rc;
+    HIP_TRY(c, lrl_launch_circle_pre(static_cast<LrlCircle*>(c->circles.p), g.circleNum, c->stream));
+    c->texW = c->texH = c->texL = 0;
+    if (s->texLayers) {
+        size_t texels = size_t(s->texWidth) * s->texHeight * s->texLayers;
+        std::vector<uchar4> t = bgrToRgbx(s->texBGR, texels);
+        if ((rc = upload(c, c->tex, t.data(), texels * 4))) return rc;
+        HIP_TRY(c, hipStreamSynchronize(c->stream));
+        c->texW = s->texWidth; c->texH = s->texHeight; c->texL = s->texLayers;
+    } else if ((rc = ensure(c, c->tex, 4))) return rc;
+    c->cubeSize = 0;
+    if (s->cubeSize) {
+        size_t face = size_t(s->cubeSize) * s->cubeSize;
+        std::vector<uchar4> t(face * 6);
+        for (int f = 0; f < 6; ++f) {
+            std::vector<uchar4> one = bgrToRgbx(s->cubeBGR[f], face);
+            std::copy(one.begin(), one.end(), t.begin() + size_t(f) * face);
+        }
+        if ((rc = upload(c, c->cube, t.data(), t.size() * 4))) return rc;
+        HIP_TRY(c, hipStreamSynchronize(c->stream));
+        c->cubeSize = s->cubeSize;
+    } else if ((rc = ensure(c, c->cube, 4))) return rc;
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    c->nodeNum = s->bvhNodeNum;
+    c->bvhDepth = depth;
+    c->haveScene = true;
+    return LRL_OK;
+}
+
+int lrl_scene_update_triangles(LrlContext* c, uint32_t first, uint32_t count, const LrlTriangle* tris) {
+    if (!c || (count && !tris)) return LRL_ERR_INVALID_ARG;
+    if (!c->haveScene) return fail(c, LRL_ERR_NO_SCENE, "no scene uploaded");
+    if (uint64_t(first) + count > c->num.triangleNum) return fail(c, LRL_ERR_INVALID_ARG, "triangle range out of bounds");
+    HIP_TRY(c, hipSetDevice(c->device));
+    return runTrianglePre(c, first, count, tris);
+}
+
+int lrl_scene_read_triangles_gpu(LrlContext* c, uint32_t first, uint32_t count, LrlTriangleGPU* out) {
+    if (!c || (count && !out)) return LRL_ERR_INVALID_ARG;
+    if (!c->haveScene) return fail(c, LRL_ERR_NO_SCENE, "no scene uploaded");
+    if (uint64_t(first) + count > c->num.triangleNum) return fail(c, LRL_ERR_INVALID_ARG, "triangle range out of bounds");
+    HIP_TRY(c, hipSetDevice(c->device));
+    std::vector<float4> hot(size_t(count) * 4);
+    std::vector<LrlTriCold> cold(count);
+    if (count) {
+        HIP_TRY(c, hipMemcpy(hot.data(), static_cast<const float4*>(c->triHot.p) + size_t(first) * 4, hot.size() * sizeof(float4), hipMemcpyDeviceToHost));
+        HIP_TRY(c, hipMemcpy(cold.data(), static_cast<const LrlTriCold*>(c->triCold.p) + first, cold.size() * sizeof(LrlTriCold), hipMemcpyDeviceToHost));
+    }
+    for (uint32_t i = 0; i < count; ++i) {
+        LrlTriangleGPU& t = out[i];
+        std::memset(&t, 0, sizeof(t));
+        const float4* h = &hot[size_t(i) * 4];
+        t.plane[0] = h[0].x; t.plane[1] = h[0].y; t.plane[2] = h[0].z; t.plane[3] = h[0].w;
+        t.p1[0] = h[1].x; t.p1[1] = h[1].y; t.p1[2] = h[1].z;
+        t.k1[0] = h[1].w; t.k1[1] = h[2].x; t.k1[2] = h[2].y;
+        t.k2[0] = h[2].z; t.k2[1] = h[2].w; t.k2[2] = h[3].x;
+        std::memcpy(t.uv1, cold[i].uv1, 8); std::memcpy(t.uv2, cold[i].uv2, 8); std::memcpy(t.uv3, cold[i].uv3, 8);
+        if (cold[i].material >= c->materialTable.size()) return fail(c, LRL_ERR_DEVICE, "material index corrupt");
+        t.color = c->materialTable[cold[i].material];
+    }
+    return LRL_OK;
+}
+
+int lrl_scene_read_circles(LrlContext* c, uint32_t first, uint32_t count, LrlCircle* out) {
+    if (!c || (count && !out)) return LRL_ERR_INVALID_ARG;
+    if (!c->haveScene) return fail(c, LRL_ERR_NO_SCENE, "no scene uploaded");
+    if (uint64_t(first) + count > c->num.circleNum) return fail(c, LRL_ERR_INVALID_ARG, "circle range out of bounds");
+    HIP_TRY(c, hipSetDevice(c->device));
+    if (count) HIP_TRY(c, hipMemcpy(out, static_cast<const LrlCircle*>(c->circles.p) + first, size_t(count) * sizeof(LrlCircle), hipMemcpyDeviceToHost));
+    return LRL_OK;
+}
+
+int lrl_set_camera(LrlContext* c, const LrlTrans* trans, uint32_t width, uint32_t height) {
+    if (!c || !trans || !width || !height || width > 65536 || height > 65536) return LRL_ERR_INVALID_ARG;
+    c->trans = *trans;
+    c->width = width; c->height = height;
+    c->haveCamera = true;
+    return LRL_OK;
+}
+
+int lrl_set_decay_origin(LrlContext* c, const float d[4]) {
+    if (!c || !d) return LRL_ERR_INVALID_ARG;
+    std::memcpy(c->decayOrigin, d, 16);
+    return LRL_OK;
+}
+
+int lrl_compute_decay_origin(LrlContext* c, uint32_t variant, LrlDecayOrigin* out) {
+    if (!c || variant > LRL_VARIANT_POOL) return LRL_ERR_INVALID_ARG;
+    if (!c->haveScene || !c->haveCamera) return fail(c, LRL_ERR_NO_SCENE, "scene and camera must be set first");
+    HIP_TRY(c, hipSetDevice(c->device));
+    int rc = upload(c, c->transDev, &c->trans, sizeof(LrlTrans));
+    if (rc) return rc;
+    if ((rc = ensure(c, c->decayDev, sizeof(LrlDecayOrigin)))) return rc;
+    KScene k;
+    fillKScene(c, k);
+    HIP_TRY(c, lrl_launch_decay_origin(k, static_cast<const LrlTrans*>(c->transDev.p), c->bvhDepth + 1, variant == LRL_VARIANT_POOL,
+                                       static_cast<LrlDecayOrigin*>(c->decayDev.p), c->stream));
+    LrlDecayOrigin h;
+    HIP_TRY(c, hipMemcpyAsync(&h, c->decayDev.p, sizeof(h), hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    std::memcpy(c->decayOrigin, h.decayOrigin, 16);
+    if (out) *out = h;
+    return LRL_OK;
+}
+
+static int renderImpl(LrlContext* c, const LrlRenderParams* p, float* rgbaDev, uint32_t* hitDev, hipStream_t stream, uint32_t rows) {
+    const uint32_t spp = p->spp;
+    uint32_t s0 = p->sampleBegin, s1 = p->sampleEnd;
+    if (s0 == 0 && s1 == 0) s1 = spp;
+    // per-sample camera: the jitter is the shear of `trans`; computed here in float like the host helper
+    std::vector<LrlTrans> tr(spp, c->trans);
+    if (p->jitter) {
+        for (uint32_t s = 0; s < spp; ++s) {
+            float dx = p->jitter[s * 2], dy = p->jitter[s * 2 + 1];
+            if (dx == 0.0f && dy == 0.0f) continue;
+            for (int i = 0; i < 3; ++i)
+                tr[s].trans[i][2] = c->trans.trans[i][2] + (c->trans.trans[i][0] * (2.0f * dx / c->trans.z0) + c->trans.trans[i][1] * (2.0f * dy / c->trans.z0));
+        }
+    }
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    int rc = ensure(c, c->transDev, tr.size() * sizeof(LrlTrans));
+    if (rc) return rc;
+    HIP_TRY(c, hipMemcpyAsync(c->transDev.p, tr.data(), tr.size() * sizeof(LrlTrans), hipMemcpyHostToDevice, stream));
+    HIP_TRY(c, hipStreamSynchronize(stream));   // `tr` is a local
+    unsigned long long* ctr = nullptr;
+    if (p->flags & LRL_FLAG_COUNTERS) {
+        if ((rc = ensure(c, c->counterDev, LRL_CTR_COUNT * 8))) return rc;
+        HIP_TRY(c, hipMemsetAsync(c->counterDev.p, 0, LRL_CTR_COUNT * 8, stream));
+        ctr = static_cast<unsigned long long*>(c->counterDev.p);
+    }
+    KScene k;
+    fillKScene(c, k);
+    KFrame f;
+    f.trans = static_cast<const LrlTrans*>(c->transDev.p);
+    f.width = c->width; f.height = c->height;
+    f.rowBegin = p->rowBegin; f.rowEnd = p->rowBegin + rows;
+    f.sampleBegin = s0; f.sampleEnd = s1; f.spp = spp;
+    f.maxDepth = p->maxDepth;
+    f.stackEntries = c->bvhDepth + 1;
+    HIP_TRY(c, hipEventRecord(c->evStart, stream));
+    if (p->mode == LRL_MODE_FAST)
+        HIP_TRY(c, lrl_launch_render_fast(k, f, reinterpret_cast<float4*>(rgbaDev), reinterpret_cast<uint2*>(hitDev), ctr, p->variant == LRL_VARIANT_POOL, stream));
+    else
+        HIP_TRY(c, lrl_launch_render_parity(k, f, reinterpret_cast<float4*>(rgbaDev), reinterpret_cast<uint2*>(hitDev), ctr, p->variant == LRL_VARIANT_POOL, stream));
+    HIP_TRY(c, hipEventRecord(c->evStop, stream));
+    c->timed = true;
+    return LRL_OK;
+}
+
+static int checkRender(LrlContext* c, const LrlRenderParams* p, uint32_t& rows) {
+    if (!c || !p) return LRL_ERR_INVALID_ARG;
+    if (!c->haveScene || !c->haveCamera) return fail(c, LRL_ERR_NO_SCENE, "scene and camera must be set before rendering");
+    if (p->maxDepth < 1 || p->maxDepth > LRL_MAX_RAY_DEPTH) return fail(c, LRL_ERR_LIMIT, "maxDepth must be 1..LRL_MAX_RAY_DEPTH");
+    if (p->variant > LRL_VARIANT_POOL || p->mode > LRL_MODE_FAST) return fail(c, LRL_ERR_INVALID_ARG, "unknown variant / mode");
+    if (p->spp < 1 || p->spp > LRL_MAX_SPP) return fail(c, LRL_ERR_LIMIT, "spp must be 1..LRL_MAX_SPP");
+    uint32_t r0 = p->rowBegin, r1 = p->rowEnd;
+    if (r0 == 0 && r1 == 0) r1 = c->height;
+    if (r0 >= r1 || r1 > c->height) return fail(c, LRL_ERR_INVALID_ARG, "row range invalid");
+    if (!(p->sampleBegin == 0 && p->sampleEnd == 0) && (p->sampleBegin >= p->sampleEnd || p->sampleEnd > p->spp))
+        return fail(c, LRL_ERR_INVALID_ARG, "sample range invalid");
+    rows = r1 - r0;
+    return LRL_OK;
+}
+
+int lrl_render_async(LrlContext* c, const LrlRenderParams* p, float* rgbaDev, uint32_t* hitDev, void* hipStream) {
+    uint32_t rows = 0;
+    int rc = checkRender(c, p, rows);
+    if (rc) return rc;
+    if (!rgbaDev) return fail(c, LRL_ERR_INVALID_ARG, "rgba_out is null");
+    HIP_TRY(c, hipSetDevice(c->device));
+    return renderImpl(c, p, rgbaDev, hitDev, hipStream ? static_cast<hipStream_t>(hipStream) : c->stream, rows);
+}
+
+int lrl_sync(LrlContext* c) {
+    if (!c) return LRL_ERR_INVALID_ARG;
+    HIP_TRY(c, hipSetDevice(c->device));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    return LRL_OK;
+}
+
+int lrl_render(LrlContext* c, const LrlRenderParams* p, float* rgba, uint32_t* hit) {
+    uint32_t rows = 0;
+    int rc = checkRender(c, p, rows);
+    if (rc) return rc;
+    if (!rgba) return fail(c, LRL_ERR_INVALID_ARG, "rgba_out is null");
+    HIP_TRY(c, hipSetDevice(c->device));
+    const bool dev = (p->flags & LRL_FLAG_OUT_DEVICE) != 0;
+    const size_t px = size_t(rows) * c->width;
+    float* o = rgba;
+    uint32_t* h = hit;
+    if (!dev) {
+        if ((rc = ensure(c, c->outDev, px * 16))) return rc;
+        o = static_cast<float*>(c->outDev.p);
+        if (hit) {
+            if ((rc = ensure(c, c->hitDev, px * 8))) return rc;
+            h = static_cast<uint32_t*>(c->hitDev.p);
+        }
+    }
+    rc = renderImpl(c, p, o, h, c->stream, rows);
+    if (rc) return rc;
+    if (!dev) {
+        HIP_TRY(c, hipMemcpyAsync(rgba, o, px * 16, hipMemcpyDeviceToHost, c->stream));
+        if (hit) HIP_TRY(c, hipMemcpyAsync(hit, h, px * 8, hipMemcpyDeviceToHost, c->stream));
+    }
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    if (p->flags & LRL_FLAG_COUNTERS) {
+        unsigned long long v[LRL_CTR_COUNT];
+        HIP_TRY(c, hipMemcpy(v, c->counterDev.p, sizeof(v), hipMemcpyDeviceToHost));
+        c->counters.raysPrimary = v[LRL_CTR_PRIMARY]; c->counters.raysReflect = v[LRL_CTR_REFLECT];
+        c->counters.raysRefract = v[LRL_CTR_REFRACT]; c->counters.raysShadow = v[LRL_CTR_SHADOW];
+        c->counters.nodeVisits = v[LRL_CTR_NODES]; c->counters.triTests = v[LRL_CTR_TRI]; c->counters.sphereTests = v[LRL_CTR_SPH];
+        c->counters.otherTests = v[LRL_CTR_OTHER]; c->counters.primaryHits = v[LRL_CTR_PRIMARY_HITS];
+    }
+    return LRL_OK;
+}
+
+int lrl_get_counters(LrlContext* c, LrlCounters* out) {
+    if (!c || !out) return LRL_ERR_INVALID_ARG;
+    *out = c->counters;
+    return LRL_OK;
+}
+
+int lrl_last_kernel_ms(LrlContext* c, float* ms) {
+    if (!c || !ms) return LRL_ERR_INVALID_ARG;
+    if (!c->timed) return fail(c, LRL_ERR_NO_SCENE, "nothing rendered yet");
+    HIP_TRY(c, hipSetDevice(c->device));
+    HIP_TRY(c, hipEventSynchronize(c->evStop));
+    HIP_TRY(c, hipEventElapsedTime(ms, c->evStart, c->evStop));
+    return LRL_OK;
+}
+
+int lrl_scene_device_bytes(LrlContext* c, uint64_t out[4]) {
+    if (!c || !out) return LRL_ERR_INVALID_ARG;
+    out[0] = uint64_t(c->nodeNum) * 32;
+    out[1] = uint64_t(c->num.triangleNum) * 64;
+    out[2] = uint64_t(c->num.triangleNum) * sizeof(LrlTriCold) + c->materialTable.size() * sizeof(LrlColor);
+    out[3] = uint64_t(c->num.sphereNum + c->num.circleNum + c->num.cylinderNum + c->num.coneNum) * 128 + uint64_t(c->num.pointLightNum) * 32 +
+             uint64_t(c->texW) * c->texH * c->texL * 4 + uint64_t(c->cubeSize) * c->cubeSize * 24;
+    return LRL_OK;
+}
+
+}  // extern "C"

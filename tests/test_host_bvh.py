@@ -1,0 +1,151 @@
+"""CPU-only: the host-side scene / BVH / camera library (raytracing_amd/host), which restates the
+reference's missing <RayTracing/_RayTracing.h>.  Invariants from SURVEY §4."""
+import os
+
+import numpy as np
+import pytest
+
+from conftest import GOLDEN
+from raytracing_amd import abi, host, scenes
+
+
+def walk(bvh):
+    """-> (depth per node, parent per node, visit order) following leftChild/rightChild from the root."""
+    n = bvh.shape[0]
+    depth = np.full(n, -1)
+    parent = np.full(n, -1)
+    st = [(0, 0, 0)]
+    while st:
+        i, d, p = st.pop()
+        assert depth[i] == -1, "node reachable twice"
+        depth[i], parent[i] = d, p
+        if bvh["rightChild"][i]:
+            st.append((int(bvh["rightChild"][i]), d + 1, i))
+        if bvh["leftChild"][i]:
+            st.append((i + 1, d + 1, i))
+    return depth, parent
+
+
+def check_invariants(m):
+    a = m.arrays()
+    bvh = a["bvh"]
+    n = bvh.shape[0]
+    depth, parent = walk(bvh)
+    assert (depth >= 0).all(), "every node reachable"
+    assert (bvh["father"][1:] == parent[1:]).all() and bvh["father"][0] == 0
+    info = m.bvh_info()
+    assert depth.max() == info["max_depth"]
+    inner = bvh["leftChild"] != 0
+    assert ((bvh["rightChild"] == 0) | inner).all()
+    # child boxes inside parent boxes
+    for i in np.nonzero(inner)[0]:
+        for c in ([i + 1] + ([int(bvh["rightChild"][i])] if bvh["rightChild"][i] else [])):
+            assert (bvh["min"][c] >= bvh["min"][i]).all() and (bvh["max"][c] <= bvh["max"][i]).all()
+    # every primitive exactly once
+    counts = {2: len(a["triangles"]), 3: len(a["spheres"]), 4: len(a["circles"]), 5: len(a["cylinders"]), 6: len(a["cones"])}
+    for g, cnt in counts.items():
+        idx = np.sort(bvh["geometryNum"][bvh["geometry"] == g])
+        assert np.array_equal(idx, np.arange(cnt)), g
+    assert set(np.unique(bvh["geometry"])) <= {0, 2, 3, 4, 5, 6}
+    leaves = ~inner
+    assert (bvh["geometry"][leaves] != 0).all() and (bvh["axis"][leaves] == 0).all()
+    assert (bvh["axis"] <= 2).all()
+    return depth
+
+
+def test_default_scene_counts_and_bvh(default_model):
+    a = default_model.arrays()
+    # BVH/BVH.cpp:280-703: 5x12 boxes + 4 mirror + 5x6 "three" = 94 triangles, 5 spheres, 1+10+5 circles, 5 cylinders, 5 cones, 3 lights
+    assert [len(a[k]) for k in ("triangles", "spheres", "circles", "cylinders", "cones", "pointLights")] == [94, 5, 16, 5, 5, 3]
+    depth = check_invariants(default_model)
+    assert depth.max() <= 32          # the reference's traversal trail is two 32-bit masks
+    assert default_model.bvh_info()["fallback_splits"] == 0
+    z = np.load(os.path.join(GOLDEN, "bvh_default_scene.npz"))
+    assert a["bvh"].tobytes() == z["bvh"].tobytes(), "builder output changed: regenerate the goldens"
+
+
+def test_add_cone_and_cylinder_are_composite():
+    m = host.HostModel()
+    cyl = np.zeros(1, dtype=abi.CYLINDER)
+    cyl["c"], cyl["r2"], cyl["n"], cyl["l"], cyl["e1"] = (1, 2, 3), 4.0, (0, 0, 1), 2.0, (1, 0, 0)
+    m.add_cylinder(cyl)
+    cone = np.zeros(1, dtype=abi.CONE)
+    cone["c"], cone["c2"], cone["n"], cone["l2"], cone["e1"] = (0, 0, 7), 0.8, (0, 0, -1), 4.0, (1, 0, 0)
+    m.add_cone(cone)
+    m.data_init()
+    a = m.arrays()
+    assert len(a["circles"]) == 3 and len(a["cylinders"]) == 1 and len(a["cones"]) == 1
+    np.testing.assert_allclose(a["circles"]["sphere"][0], [1, 2, 3, 4])
+    np.testing.assert_allclose(a["circles"]["sphere"][1], [1, 2, 5, 4])
+    np.testing.assert_allclose(a["circles"]["sphere"][2], [0, 0, 7 - np.sqrt(3.2), 0.8], rtol=1e-6)
+    check_invariants(m)
+
+
+def test_stl_winding_follows_stored_normal(tmp_path):
+    # one triangle stored clockwise against its normal: addSTL must swap v2/v3 (BVH.exe@0x140008c30)
+    p = tmp_path / "t.stl"
+    rec = np.zeros(2, dtype=np.dtype([("n", "<f4", 3), ("v", "<f4", (3, 3)), ("a", "<u2")]))
+    rec["n"] = [(0, 0, 1), (0, 0, 1)]
+    rec["v"][0] = [(0, 0, 0), (1, 0, 0), (0, 1, 0)]     # ccw seen from +z: kept
+    rec["v"][1] = [(0, 0, 0), (0, 1, 0), (1, 0, 0)]     # cw: swapped
+    with open(p, "wb") as f:
+        f.write(b"\0" * 80 + np.uint32(2).tobytes() + rec.tobytes())
+    m = host.HostModel()
+    m.add_stl(str(p), abi.color(d=1.0))
+    m.data_init()
+    t = m.arrays()["triangles"]
+    np.testing.assert_array_equal(t["p2"], [(1, 0, 0), (1, 0, 0)])
+    np.testing.assert_array_equal(t["p3"], [(0, 1, 0), (0, 1, 0)])
+    np.testing.assert_array_equal(t["uv2"], [(1, 0), (1, 0)])
+    np.testing.assert_array_equal(t["uv3"], [(0, 1), (0, 1)])
+
+
+def test_camera_z0_and_start_pose(default_model):
+    m = host.HostModel()
+    t = m.camera(1024)[0]
+    assert abs(float(t["z0"]) - (-1024 / np.tan(np.pi / 6))) < 1e-3        # -1773.62
+    np.testing.assert_array_equal(t["trans"][:, :3], np.eye(3, dtype=np.float32))
+    np.testing.assert_array_equal(t["r0"], [0, 0, 30])
+
+
+def test_shear_equals_subpixel_offset():
+    m = host.HostModel()
+    m.camera_look_at(60, (3, -20, 10), (0, 0, 2))
+    t = m.camera(200)
+    s = host.sheared(t, 0.25, -0.4)[0]
+    T, S = t[0]["trans"][:, :3].astype(np.float64), s["trans"][:, :3].astype(np.float64)
+    v = np.array([11.0, -7.0, float(t[0]["z0"])])
+    np.testing.assert_allclose(S @ v, T @ (v + [0.5, -0.8, 0]), rtol=1e-5)
+
+
+def test_empty_scene_builds_a_dead_node():
+    m = host.HostModel()
+    m.data_init()
+    a = m.arrays()
+    assert len(a["bvh"]) == 1 and a["bvh"]["geometry"][0] == 0 and a["bvh"]["leftChild"][0] == 0
+
+
+@pytest.mark.parametrize("builder", ["reference", "median"])
+def test_bunny_bvh_invariants(builder):
+    m = scenes.mesh_scene(subdivisions=0, builder=builder)
+    depth = check_invariants(m)
+    n = m.bvh_info()
+    if builder == "median":
+        assert depth.max() <= 18 and n["nodes"] == 2 * (77560 + 1) - 1
+    assert len(m.arrays()["triangles"]) == 77560
+
+
+def test_coincident_centres_terminate():
+    # SURVEY App. A "termination hazard": identical centres, no leaf box equal to the union
+    m = host.HostModel()
+    t = np.zeros(8, dtype=abi.TRIANGLE)
+    for i in range(8):
+        s = 1.0 + i
+        ang = i * 0.7
+        t["p1"][i] = (-s * np.cos(ang), -s * np.sin(ang), 0)
+        t["p2"][i] = (s * np.cos(ang), s * np.sin(ang), 0)
+        t["p3"][i] = (0, 0, 0)
+    t["color"] = abi.color(d=1.0)
+    m.add_triangles(t)
+    m.data_init()
+    check_invariants(m)
