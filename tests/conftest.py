@@ -29,10 +29,19 @@ def load_golden(name):
 
 
 def image_stats(a, b):
-    """a, b: [H, W, >=3] float images -> dict(rmse, max, frac_gt)"""
-    d = a[..., :3].astype(np.float64) - b[..., :3].astype(np.float64)
-    return {"rmse": float(np.sqrt(np.mean(d * d))), "max": float(np.abs(d).max()),
-            "frac_gt_1e-3": float((np.abs(d).max(axis=-1) > 1e-3).mean())}
+    """a, b: [H, W, >=3] float images -> dict(rmse, max, frac_gt, nonfinite_mismatch).
+    Pixels that are non-finite in BOTH images are skipped (the reference's sphere uv is acos() of a ratio that
+    rounding can push past 1, which is NaN in GLSL, in the oracle and on the GPU alike); a pixel that is
+    non-finite in only one of them counts in `nonfinite_mismatch`, which callers bound."""
+    a3, b3 = a[..., :3].astype(np.float64), b[..., :3].astype(np.float64)
+    fa, fb = np.isfinite(a3).all(axis=-1), np.isfinite(b3).all(axis=-1)
+    both = fa & fb
+    d = (a3 - b3)[both]
+    st = {"rmse": float(np.sqrt(np.mean(d * d))) if d.size else 0.0, "max": float(np.abs(d).max()) if d.size else 0.0,
+          "frac_gt_1e-3": float((np.abs(d).max(axis=-1) > 1e-3).mean()) if d.size else 0.0,
+          "nonfinite_mismatch": float((fa != fb).mean()), "nonfinite_both": float((~fa & ~fb).mean())}
+    assert st["nonfinite_mismatch"] <= 1e-3, st
+    return st
 
 
 @pytest.fixture(scope="session")
