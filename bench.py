@@ -1,0 +1,175 @@
+#!/usr/bin/env python3
+"""bench.py — Mrays/s of the hot path on the BASELINE.json headline configuration.
+
+Workload (BASELINE.json configs[1]): Stanford bunny x 2 midpoint subdivisions
+(1 240 960 triangles) + ground disc + 1 point light, 1920x1080, 1 spp, 4 bounces.  A "step" is one
+frame: one launch of the trace kernel over every pixel, scene and camera already resident in HBM,
+image written to HBM.  rays = primary + reflection + refraction + shadow segments (device counters,
+taken by an un-timed launch of the counting variant of the same kernel and checked against the CPU
+oracle in tests/).
+
+N > 1 (torchrun, one rank per GPU): the scene is replicated; every rank renders the whole frame for
+ONE sample of an N-sample jitter table (sample-index sharding, so per-GPU work is fixed: weak
+scaling) and the partial means are summed with one RCCL all-reduce per step, inside the timed
+region.  value = rays of all ranks / max-over-ranks time.
+
+  python bench.py [--gpus N] [--steps K] [--warmup W] [--mode fast|parity] [--builder reference|median]
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+REPO = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, REPO)
+
+HBM_PEAK_GBPS = 8000.0          # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8 TB/s (spec)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--mode", default="fast", choices=["fast", "parity"])
+    ap.add_argument("--builder", default="median", choices=["reference", "median"])
+    ap.add_argument("--subdivisions", type=int, default=2)
+    ap.add_argument("--width", type=int, default=1920)
+    ap.add_argument("--height", type=int, default=1080)
+    ap.add_argument("--depth", type=int, default=4)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-rows", type=int, default=0, help="rows of the frame the CPU baseline renders (0 = auto)")
+    a = ap.parse_args()
+
+    import numpy as np
+    import torch
+    import torch.distributed as dist
+
+    from raytracing_amd import abi, host, scenes, tracer
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != a.gpus:
+        raise SystemExit(f"--gpus {a.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {a.gpus}")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU: the HIP path has no CPU fallback")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group(backend="nccl", device_id=dev)
+
+    # ---- scene: built on the host by the restated reference library, uploaded once ----
+    t0 = time.time()
+    m = scenes.mesh_scene(subdivisions=a.subdivisions, builder=a.builder)
+    build_s = time.time() - t0
+    info = m.bvh_info()
+    W, H = a.width, a.height
+    trans = m.camera(H)
+    view = m.scene_view()
+    tr = tracer.Tracer(local_rank)
+    t0 = time.time()
+    tr.scene_upload(view)
+    upload_s = time.time() - t0
+    tr.set_camera(trans, W, H)
+    tr.set_decay_origin((0, 0, 0, 1))
+    mode = abi.MODE_FAST if a.mode == "fast" else abi.MODE_PARITY
+    jitter = host.jitter_table(world) if world > 1 else None
+    samples = (rank, rank + 1) if world > 1 else None
+
+    # ---- ray / node / primitive-test counts of this rank's frame (counting variant, un-timed) ----
+    _, _ = tr.render(max_depth=a.depth, mode=mode, counters=True, jitter=jitter, samples=samples, want_hits=False)
+    cn = tr.counters()
+    rays, alg_bytes = cn.rays, cn.algorithmic_bytes()
+
+    out = torch.empty((H, W, 4), dtype=torch.float32, device=dev)
+
+    def step():
+        tr.render_device(out.data_ptr(), max_depth=a.depth, mode=mode, jitter=jitter, samples=samples)
+        if world > 1:
+            tr.sync()                       # the library renders on its own stream; the collective runs on torch's
+            dist.all_reduce(out, op=dist.ReduceOp.SUM)
+
+    for _ in range(a.warmup):
+        step()
+    tr.sync()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    tr.timing_begin()
+    t0 = time.perf_counter()
+    for _ in range(a.steps):
+        step()
+    tr.sync()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    kernel_ms_total, launches = tr.timing_end()
+
+    tot = torch.tensor([elapsed, float(rays), float(alg_bytes)], dtype=torch.float64, device=dev)
+    if world > 1:
+        mx = tot.clone()
+        dist.all_reduce(mx, op=dist.ReduceOp.MAX)
+        dist.all_reduce(tot, op=dist.ReduceOp.SUM)
+        elapsed = float(mx[0])
+        rays_all = float(tot[1])
+    else:
+        rays_all = float(rays)
+
+    if rank == 0:
+        ms_per_step = elapsed / a.steps * 1e3
+        value = rays_all * a.steps / elapsed / 1e6
+        kernel_ms = kernel_ms_total / max(launches, 1)
+        achieved = alg_bytes / (kernel_ms * 1e-3) / 1e9
+        dbytes = tr.scene_device_bytes()
+        line = {
+            "metric": "Mrays/s (whole node) at 1080p 4-bounce", "value": round(value, 2), "unit": "Mrays/s", "n_gpus": world,
+            "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(ms_per_step, 4), "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": f"C2: Stanford bunny x{a.subdivisions} subdivisions ({view.num.triangleNum} triangles) + ground disc + 1 light, "
+                                   f"{W}x{H}, 1 spp per GPU, RayTraceDepth {a.depth}",
+                       "bvh_builder": a.builder, "bvh_nodes": info["nodes"], "bvh_depth": info["max_depth"], "arithmetic": a.mode,
+                       "parallelism": "replicated scene, 1 sample index per GPU, RCCL all-reduce of the image" if world > 1 else "1 GPU",
+                       "rays_per_frame": int(rays), "host_bvh_build_s": round(build_s, 2), "scene_upload_s": round(upload_s, 2),
+                       "device_scene_bytes": dbytes},
+            "roofline": {"bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                         "frac": round(achieved / HBM_PEAK_GBPS, 5), "traffic": None, "kernel_ms": round(kernel_ms, 4),
+                         "algorithmic_bytes_per_launch": int(alg_bytes),
+                         "counts": {"node_visits": int(cn.nodeVisits), "tri_tests": int(cn.triTests), "sphere_tests": int(cn.sphereTests),
+                                    "other_tests": int(cn.otherTests), "rays": int(rays)}},
+        }
+        if not a.no_cpu_baseline and world == 1:
+            line["cpu_baseline"] = cpu_baseline(a, m, view, trans, W, H)
+        print(json.dumps(line), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+    tr.close()
+
+
+def cpu_baseline(a, m, view, trans, W, H):
+    """The CPU oracle (C++ restatement of the reference shader, OpenMP over rows) on a bounded stripe of the SAME frame."""
+    from oracle import oracle_api as O
+    cores = min(16, os.cpu_count() or 1)
+    rows = a.cpu_rows
+    if rows == 0:
+        # calibrate on 8 centre rows, then size the sample for ~15 s
+        t0 = time.perf_counter()
+        _, _, c0 = O.render(view, trans, W, H, max_depth=a.depth, rows=(H // 2 - 4, H // 2 + 4), threads=cores, want_hits=False)
+        dt = time.perf_counter() - t0
+        rows = int(max(16, min(H, 8 * 15.0 / max(dt, 1e-3))))
+    r0 = max(0, (H - rows) // 2)
+    t0 = time.perf_counter()
+    _, _, c = O.render(view, trans, W, H, max_depth=a.depth, rows=(r0, r0 + rows), threads=cores, want_hits=False)
+    dt = time.perf_counter() - t0
+    return {"value": round(c.rays / dt / 1e6, 3), "unit": "Mrays/s", "cores": cores, "kind": "port",
+            "sample": f"rows {r0}..{r0 + rows} of the same {W}x{H} frame ({c.rays} rays, {dt:.1f} s), oracle/liboracle.so with OpenMP"}
+
+
+if __name__ == "__main__":
+    main()

@@ -134,6 +134,11 @@ int lrl_sync(LrlContext* ctx);
 int lrl_get_counters(LrlContext* ctx, LrlCounters* out);   /* of the last render with LRL_FLAG_COUNTERS */
 /* duration of the trace kernel(s) of the last render, HIP events on the stream they ran on */
 int lrl_last_kernel_ms(LrlContext* ctx, float* ms);
+/* accumulate the trace-kernel durations of every render between _begin and _end (HIP event pairs on the
+ * stream each kernel ran on; _end waits for them); at most LRL_MAX_TIMED_LAUNCHES launches are kept */
+#define LRL_MAX_TIMED_LAUNCHES 4096u
+int lrl_timing_begin(LrlContext* ctx);
+int lrl_timing_end(LrlContext* ctx, double* total_ms, uint32_t* launches);
 /* device memory held for the scene (bytes), by class: nodes, triangle hot, triangle cold, other */
 int lrl_scene_device_bytes(LrlContext* ctx, uint64_t out[4]);
 

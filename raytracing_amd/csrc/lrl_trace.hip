@@ -54,6 +54,9 @@ struct LrlContext {
     DevBuf transDev, outDev, hitDev, counterDev, decayDev;
     float lastMs = 0;
     bool timed = false;
+    bool timing = false;
+    std::vector<std::pair<hipEvent_t, hipEvent_t>> timingEvents;
+    uint32_t timingUsed = 0;
     LrlCounters counters{};
 };
 
@@ -211,6 +214,7 @@ int lrl_destroy(LrlContext* c) {
     for (DevBuf* b : {&c->nodes, &c->triHot, &c->triCold, &c->materials, &c->spheres, &c->circles, &c->cylinders, &c->cones, &c->lights,
                       &c->tex, &c->cube, &c->triStage, &c->matStage, &c->transDev, &c->outDev, &c->hitDev, &c->counterDev, &c->decayDev})
         release(*b);
+    for (auto& e : c->timingEvents) { (void)hipEventDestroy(e.first); (void)hipEventDestroy(e.second); }
     if (c->evStart) (void)hipEventDestroy(c->evStart);
     if (c->evStop) (void)hipEventDestroy(c->evStop);
     if (c->stream) (void)hipStreamDestroy(c->stream);
@@ -433,13 +437,24 @@ static int renderImpl(LrlContext* c, const LrlRenderParams* p, float* rgbaDev, u
     f.sampleBegin = s0; f.sampleEnd = s1; f.spp = spp;
     f.maxDepth = p->maxDepth;
     f.stackEntries = c->bvhDepth + 1;
-    HIP_TRY(c, hipEventRecord(c->evStart, stream));
+    hipEvent_t e0 = c->evStart, e1 = c->evStop;
+    if (c->timing && c->timingUsed < LRL_MAX_TIMED_LAUNCHES) {
+        if (c->timingUsed == c->timingEvents.size()) {
+            hipEvent_t a, b;
+            HIP_TRY(c, hipEventCreate(&a));
+            HIP_TRY(c, hipEventCreate(&b));
+            c->timingEvents.emplace_back(a, b);
+        }
+        e0 = c->timingEvents[c->timingUsed].first; e1 = c->timingEvents[c->timingUsed].second;
+        ++c->timingUsed;
+    }
+    HIP_TRY(c, hipEventRecord(e0, stream));
     if (p->mode == LRL_MODE_FAST)
         HIP_TRY(c, lrl_launch_render_fast(k, f, reinterpret_cast<float4*>(rgbaDev), reinterpret_cast<uint2*>(hitDev), ctr, p->variant == LRL_VARIANT_POOL, stream));
     else
         HIP_TRY(c, lrl_launch_render_parity(k, f, reinterpret_cast<float4*>(rgbaDev), reinterpret_cast<uint2*>(hitDev), ctr, p->variant == LRL_VARIANT_POOL, stream));
-    HIP_TRY(c, hipEventRecord(c->evStop, stream));
-    c->timed = true;
+    HIP_TRY(c, hipEventRecord(e1, stream));
+    c->timed = (e0 == c->evStart);
     return LRL_OK;
 }
 
@@ -522,6 +537,30 @@ int lrl_last_kernel_ms(LrlContext* c, float* ms) {
     HIP_TRY(c, hipSetDevice(c->device));
     HIP_TRY(c, hipEventSynchronize(c->evStop));
     HIP_TRY(c, hipEventElapsedTime(ms, c->evStart, c->evStop));
+    return LRL_OK;
+}
+
+int lrl_timing_begin(LrlContext* c) {
+    if (!c) return LRL_ERR_INVALID_ARG;
+    c->timing = true;
+    c->timingUsed = 0;
+    return LRL_OK;
+}
+
+int lrl_timing_end(LrlContext* c, double* totalMs, uint32_t* launches) {
+    if (!c || !totalMs || !launches) return LRL_ERR_INVALID_ARG;
+    HIP_TRY(c, hipSetDevice(c->device));
+    double sum = 0;
+    for (uint32_t i = 0; i < c->timingUsed; ++i) {
+        float ms = 0;
+        HIP_TRY(c, hipEventSynchronize(c->timingEvents[i].second));
+        HIP_TRY(c, hipEventElapsedTime(&ms, c->timingEvents[i].first, c->timingEvents[i].second));
+        sum += ms;
+    }
+    *totalMs = sum;
+    *launches = c->timingUsed;
+    c->timing = false;
+    c->timingUsed = 0;
     return LRL_OK;
 }
 

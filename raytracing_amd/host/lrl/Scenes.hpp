@@ -147,10 +147,11 @@ inline Camera mesh(Model& m, STL const& in, unsigned subdivisions) {
     }
     double lp = 2.5 * ext;
     m.pointLights.data.pointLights += {{{lp * lp * 0.05, lp * lp * 0.05, lp * lp * 0.05}, {cx + 0.6 * lp, cy - 0.5 * lp, lp}}};
-    // camera: on the -y side, slightly above, looking at the bbox centre; camera looks down its -z
+    // camera: close on the +y side, slightly above, looking at the bbox centre (the mesh fills about a third of
+    // the frame); the camera looks down its -z
     Camera cam;
     cam.fovy = 60;
-    Math::vec3<double> target(cx, cy, cz), eye(cx + 0.35 * ext, cy - 1.55 * ext, cz + 0.55 * ext);
+    Math::vec3<double> target(cx, cy, 0.9 * cz), eye(cx + 0.15 * ext, cy + 0.72 * ext, cz + 0.36 * ext);
     Math::vec3<double> f = target - eye;                       // forward
     double fl = std::sqrt(f.dot(f)); f = f * (1 / fl);
     Math::vec3<double> up(0, 0, 1);

@@ -19,6 +19,7 @@ EXPORTS = [
     "lrl_create", "lrl_destroy", "lrl_last_error", "lrl_version", "lrl_scene_upload", "lrl_scene_update_triangles",
     "lrl_scene_read_triangles_gpu", "lrl_scene_read_circles", "lrl_set_camera", "lrl_set_decay_origin", "lrl_compute_decay_origin",
     "lrl_render", "lrl_render_async", "lrl_sync", "lrl_get_counters", "lrl_last_kernel_ms", "lrl_scene_device_bytes",
+    "lrl_timing_begin", "lrl_timing_end",
 ]
 
 
@@ -45,6 +46,8 @@ def lib():
         L.lrl_get_counters.argtypes = [C.c_void_p, C.POINTER(abi.Counters)]
         L.lrl_last_kernel_ms.argtypes = [C.c_void_p, C.POINTER(C.c_float)]
         L.lrl_scene_device_bytes.argtypes = [C.c_void_p, C.POINTER(C.c_uint64)]
+        L.lrl_timing_begin.argtypes = [C.c_void_p]
+        L.lrl_timing_end.argtypes = [C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_uint32)]
         _lib = L
     return _lib
 
@@ -152,6 +155,15 @@ class Tracer:
         ms = C.c_float()
         self._ck(self._L.lrl_last_kernel_ms(self._ctx, C.byref(ms)))
         return float(ms.value)
+
+    def timing_begin(self):
+        self._ck(self._L.lrl_timing_begin(self._ctx))
+
+    def timing_end(self):
+        """-> (total kernel ms, launches) of the renders since timing_begin()"""
+        ms, n = C.c_double(), C.c_uint32()
+        self._ck(self._L.lrl_timing_end(self._ctx, C.byref(ms), C.byref(n)))
+        return float(ms.value), int(n.value)
 
     def scene_device_bytes(self):
         v = (C.c_uint64 * 4)()
