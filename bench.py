@@ -33,7 +33,7 @@ def main():
     ap.add_argument("--steps", type=int, default=50)
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--mode", default="fast", choices=["fast", "parity"])
-    ap.add_argument("--builder", default="median", choices=["reference", "median"])
+    ap.add_argument("--builder", default="reference", choices=["reference", "median"])
     ap.add_argument("--subdivisions", type=int, default=2)
     ap.add_argument("--width", type=int, default=1920)
     ap.add_argument("--height", type=int, default=1080)
@@ -156,19 +156,21 @@ def cpu_baseline(a, m, view, trans, W, H):
     """The CPU oracle (C++ restatement of the reference shader, OpenMP over rows) on a bounded stripe of the SAME frame."""
     from oracle import oracle_api as O
     cores = min(16, os.cpu_count() or 1)
-    rows = a.cpu_rows
-    if rows == 0:
-        # calibrate on 8 centre rows, then size the sample for ~15 s
-        t0 = time.perf_counter()
-        _, _, c0 = O.render(view, trans, W, H, max_depth=a.depth, rows=(H // 2 - 4, H // 2 + 4), threads=cores, want_hits=False)
-        dt = time.perf_counter() - t0
-        rows = int(max(16, min(H, 8 * 15.0 / max(dt, 1e-3))))
+    rows = a.cpu_rows or H
     r0 = max(0, (H - rows) // 2)
-    t0 = time.perf_counter()
-    _, _, c = O.render(view, trans, W, H, max_depth=a.depth, rows=(r0, r0 + rows), threads=cores, want_hits=False)
-    dt = time.perf_counter() - t0
-    return {"value": round(c.rays / dt / 1e6, 3), "unit": "Mrays/s", "cores": cores, "kind": "port",
-            "sample": f"rows {r0}..{r0 + rows} of the same {W}x{H} frame ({c.rays} rays, {dt:.1f} s), oracle/liboracle.so with OpenMP"}
+    # repeat the stripe until ~12 s of CPU work have been timed (at least twice)
+    rays, dt, reps = 0, 0.0, 0
+    while dt < 12.0 or reps < 2:
+        t0 = time.perf_counter()
+        _, _, c = O.render(view, trans, W, H, max_depth=a.depth, rows=(r0, r0 + rows), threads=cores, want_hits=False)
+        dt += time.perf_counter() - t0
+        rays += c.rays
+        reps += 1
+        if reps >= 200:
+            break
+    return {"value": round(rays / dt / 1e6, 3), "unit": "Mrays/s", "cores": cores, "kind": "port",
+            "sample": f"rows {r0}..{r0 + rows} of the same {W}x{H} frame rendered {reps} times ({rays} rays, {dt:.1f} s), "
+                      f"oracle/liboracle.so, OpenMP over rows"}
 
 
 if __name__ == "__main__":
