@@ -8,7 +8,7 @@ hipError_t lrl_launch_render_fast(const KScene& sc, const KFrame& fr, float4* ou
                                   hipStream_t stream) {
     uint32_t tx = (fr.width + LRL_TILE - 1) / LRL_TILE, ty = (fr.rowEnd - fr.rowBegin + LRL_TILE - 1) / LRL_TILE;
     dim3 grid(tx * ty), block(LRL_BLOCK_THREADS);
-    size_t lds = size_t(fr.stackEntries) * LRL_BLOCK_THREADS * sizeof(uint32_t);
+    size_t lds = size_t(fr.stackEntries) * LRL_BLOCK_THREADS * 8;
     using namespace lrl_fast;
     if (counters) {
         if (pool) hipLaunchKernelGGL((renderKernel<true, true>), grid, block, lds, stream, sc, fr, out, hit, counters);

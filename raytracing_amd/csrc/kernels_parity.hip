@@ -48,7 +48,7 @@ __global__ __launch_bounds__(256) void circlePreKernel(LrlCircle* __restrict__ c
 
 }  // namespace lrl_parity
 
-static size_t ldsBytes(const KFrame& fr) { return size_t(fr.stackEntries) * LRL_BLOCK_THREADS * sizeof(uint32_t); }
+static size_t ldsBytes(const KFrame& fr) { return size_t(fr.stackEntries) * LRL_BLOCK_THREADS * 8; }
 static dim3 gridFor(const KFrame& fr) {
     uint32_t tx = (fr.width + LRL_TILE - 1) / LRL_TILE, ty = (fr.rowEnd - fr.rowBegin + LRL_TILE - 1) / LRL_TILE;
     return dim3(tx * ty);
@@ -71,10 +71,10 @@ hipError_t lrl_launch_render_parity(const KScene& sc, const KFrame& fr, float4* 
 
 hipError_t lrl_launch_decay_origin(const KScene& sc, const LrlTrans* trans, uint32_t stackEntries, bool pool, LrlDecayOrigin* out,
                                    hipStream_t stream) {
-    size_t lds = size_t(stackEntries) * LRL_BLOCK_THREADS * sizeof(uint32_t);
+    size_t lds = size_t(stackEntries) * LRL_BLOCK_THREADS * 8;
     using namespace lrl_parity;
-    if (pool) hipLaunchKernelGGL((decayOriginKernel<true>), dim3(1), dim3(LRL_BLOCK_THREADS), lds, stream, sc, trans, out);
-    else hipLaunchKernelGGL((decayOriginKernel<false>), dim3(1), dim3(LRL_BLOCK_THREADS), lds, stream, sc, trans, out);
+    if (pool) hipLaunchKernelGGL((decayOriginKernel<true>), dim3(1), dim3(LRL_BLOCK_THREADS), lds, stream, sc, trans, stackEntries, out);
+    else hipLaunchKernelGGL((decayOriginKernel<false>), dim3(1), dim3(LRL_BLOCK_THREADS), lds, stream, sc, trans, stackEntries, out);
     return hipGetLastError();
 }
 

@@ -2,11 +2,14 @@
 // (lrl_trace.hip) and the two kernel translation units (kernels_parity.hip, kernels_fast.hip).
 //
 // HBM layout (built by lrl_scene_upload from the reference's AoS records):
-//   nodes     2 x float4 per BVH node (32 B):  {min.xyz, bits A} {max.xyz, bits B}
-//               A = rightChild (30 bits, 0 = none) | axis << 30
-//               B = geometryNum (28 bits) | leftChild flag << 28 | geometry type << 29
-//             father / blank of the reference's 64-B node are dropped: traversal keeps a per-lane
-//             stack of pending far children in LDS instead of the reference's parent-pointer trail.
+//   recs      4 x float4 per INNER node (64 B, one half cache line), boxes of both children in the parent:
+//               {left.min, leftRef} {left.max, rightRef} {right.min, own primitive} {right.max, split axis}
+//             a child ref is LRL_REF_NONE, an inner-record index, or LRL_REF_LEAF | primitive, where
+//             primitive = type << 28 | index; "own primitive" is the primitive the reference's builder
+//             parks in an inner node (0 = none).  Record 0 is a virtual parent of the root.  Leaves have no
+//             record: a leaf visit costs no node fetch.  father / blank of the reference's 64-B node are
+//             dropped: traversal keeps a per-lane stack of pending far children in LDS instead of the
+//             reference's parent-pointer trail.
 //   triHot    4 x float4 per triangle (64 B, one half cache line): plane | p1,k1.x | k1.yz,k2.xy | k2.z
 //   triCold   32 B per triangle: uv1 uv2 uv3, material index   (read once per accepted hit)
 //   materials 80-B Color records, de-duplicated on upload (a mesh usually has a handful)
@@ -26,14 +29,19 @@ struct LrlTriCold {
 };
 static_assert(sizeof(LrlTriCold) == 32, "TriCold");
 
-#define LRL_NODE_RIGHT_MASK 0x3fffffffu
-#define LRL_NODE_AXIS_SHIFT 30
-#define LRL_NODE_NUM_MASK 0x0fffffffu
-#define LRL_NODE_LEFT_BIT 0x10000000u
-#define LRL_NODE_GEOM_SHIFT 29
+#define LRL_REF_NONE 0xffffffffu
+#define LRL_REF_LEAF 0x80000000u
+#define LRL_PRIM_TYPE_SHIFT 28
+#define LRL_PRIM_INDEX_MASK 0x0fffffffu
+#ifndef LRL_LDS_STACK_ENTRIES
+#define LRL_LDS_STACK_ENTRIES 12u   /* pending far children per lane kept in LDS; deeper entries spill to scratch */
+#endif
+#ifndef LRL_MIN_WAVES_PER_SIMD
+#define LRL_MIN_WAVES_PER_SIMD 4    /* __launch_bounds__ second argument of the trace kernel (register budget) */
+#endif
 
 struct KScene {
-    const float4* nodes;
+    const float4* recs;
     const float4* triHot;
     const LrlTriCold* triCold;
     const LrlColor* materials;
@@ -57,7 +65,7 @@ struct KFrame {
     uint32_t sampleBegin, sampleEnd;   // samples rendered by this launch
     uint32_t spp;                      // divisor of the mean
     uint32_t maxDepth;
-    uint32_t stackEntries;             // LDS traversal-stack entries per lane (>= BVH depth + 1)
+    uint32_t stackEntries;             // LDS traversal-stack entries per lane: min(BVH depth + 1, LRL_LDS_STACK_ENTRIES)
 };
 
 enum { LRL_CTR_PRIMARY = 0, LRL_CTR_REFLECT, LRL_CTR_REFRACT, LRL_CTR_SHADOW, LRL_CTR_NODES, LRL_CTR_TRI, LRL_CTR_SPH,

@@ -41,7 +41,7 @@ struct LrlContext {
     // scene
     bool haveScene = false, haveCamera = false;
     LrlGeometryNum num{};
-    uint32_t nodeNum = 0, bvhDepth = 0;
+    uint32_t nodeNum = 0, recNum = 0, bvhDepth = 0;
     DevBuf nodes, triHot, triCold, materials, spheres, circles, cylinders, cones, lights, tex, cube, triStage, matStage;
     uint32_t texW = 0, texH = 0, texL = 0, cubeSize = 0;
     std::vector<LrlColor> materialTable;
@@ -103,7 +103,7 @@ uint32_t internMaterial(LrlContext* c, const LrlColor& col) {
 // Structural checks of the caller's BVH so that no lane can index outside a buffer or overrun its stack.
 int validateBVH(LrlContext* c, const LrlSceneView* s, uint32_t& depthOut) {
     const uint32_t N = s->bvhNodeNum;
-    if (N == 0 || N > LRL_NODE_RIGHT_MASK) return fail(c, LRL_ERR_INVALID_ARG, "bvhNodeNum out of range");
+    if (N == 0 || N >= LRL_REF_LEAF) return fail(c, LRL_ERR_INVALID_ARG, "bvhNodeNum out of range");
     const uint32_t counts[7] = {0, 0, s->num.triangleNum, s->num.sphereNum, s->num.circleNum, s->num.cylinderNum, s->num.coneNum};
     for (uint32_t i = 0; i < N; ++i) {
         const LrlBVHNode& n = s->bvh[i];
@@ -114,7 +114,7 @@ int validateBVH(LrlContext* c, const LrlSceneView* s, uint32_t& depthOut) {
         if (n.axis > 2) return fail(c, LRL_ERR_INVALID_ARG, "BVH: axis > 2");
         if (n.geometry != 0) {
             if (n.geometry < 2 || n.geometry > 6) return fail(c, LRL_ERR_INVALID_ARG, "BVH: unknown geometry type");
-            if (n.geometryNum >= counts[n.geometry] || n.geometryNum > LRL_NODE_NUM_MASK)
+            if (n.geometryNum >= counts[n.geometry] || n.geometryNum > LRL_PRIM_INDEX_MASK)
                 return fail(c, LRL_ERR_INVALID_ARG, "BVH: geometryNum out of range");
         }
     }
@@ -138,7 +138,7 @@ int validateBVH(LrlContext* c, const LrlSceneView* s, uint32_t& depthOut) {
 }
 
 void fillKScene(const LrlContext* c, KScene& k) {
-    k.nodes = static_cast<const float4*>(c->nodes.p);
+    k.recs = static_cast<const float4*>(c->nodes.p);
     k.triHot = static_cast<const float4*>(c->triHot.p);
     k.triCold = static_cast<const LrlTriCold*>(c->triCold.p);
     k.materials = static_cast<const LrlColor*>(c->materials.p);
@@ -231,7 +231,7 @@ int lrl_scene_upload(LrlContext* c, const LrlSceneView* s) {
     if ((g.sphereNum && !s->spheres) || (g.circleNum && !s->circles) || (g.cylinderNum && !s->cylinders) || (g.coneNum && !s->cones) ||
         (g.pointLightNum && !s->pointLights) || !s->bvh)
         return fail(c, LRL_ERR_INVALID_ARG, "null array with non-zero count");
-    if (g.triangleNum > LRL_NODE_NUM_MASK) return fail(c, LRL_ERR_LIMIT, "more than 2^28 triangles");
+    if (g.triangleNum > LRL_PRIM_INDEX_MASK) return fail(c, LRL_ERR_LIMIT, "more than 2^28 triangles");
     if (s->texLayers && (!s->texBGR || !s->texWidth || !s->texHeight)) return fail(c, LRL_ERR_INVALID_ARG, "texture array incomplete");
     if (s->cubeSize) for (int i = 0; i < 6; ++i) if (!s->cubeBGR[i]) return fail(c, LRL_ERR_INVALID_ARG, "cube face missing");
     uint32_t depth = 0;
@@ -239,17 +239,43 @@ int lrl_scene_upload(LrlContext* c, const LrlSceneView* s) {
     if (rc) return rc;
     c->haveScene = false;
 
-    // nodes: 64-B reference records -> 32-B traversal records
+    // nodes: the reference's 64-B own-box records -> 64-B inner records that hold both children's boxes
+    uint32_t recCount = 1;
     {
-        std::vector<float4> packed(size_t(s->bvhNodeNum) * 2);
-        for (uint32_t i = 0; i < s->bvhNodeNum; ++i) {
+        const uint32_t N = s->bvhNodeNum;
+        std::vector<uint32_t> recOf(N, 0);
+        for (uint32_t i = 0; i < N; ++i) if (s->bvh[i].bound.leftChild) recOf[i] = recCount++;
+        auto refOf = [&](uint32_t i) -> uint32_t {
             const LrlBVHNode& n = s->bvh[i];
-            uint32_t wa = (uint32_t(n.bound.rightChild) & LRL_NODE_RIGHT_MASK) | (n.axis << LRL_NODE_AXIS_SHIFT);
-            uint32_t wb = (n.geometryNum & LRL_NODE_NUM_MASK) | (n.bound.leftChild ? LRL_NODE_LEFT_BIT : 0u) | (n.geometry << LRL_NODE_GEOM_SHIFT);
-            float fa, fb;
-            std::memcpy(&fa, &wa, 4); std::memcpy(&fb, &wb, 4);
-            packed[size_t(i) * 2] = make_float4(n.bound.min[0], n.bound.min[1], n.bound.min[2], fa);
-            packed[size_t(i) * 2 + 1] = make_float4(n.bound.max[0], n.bound.max[1], n.bound.max[2], fb);
+            if (n.bound.leftChild) return recOf[i];
+            return LRL_REF_LEAF | (n.geometry << LRL_PRIM_TYPE_SHIFT) | (n.geometryNum & LRL_PRIM_INDEX_MASK);
+        };
+        auto asf = [](uint32_t v) { float f; std::memcpy(&f, &v, 4); return f; };
+        std::vector<float4> packed(size_t(recCount) * 4);
+        {   // record 0: virtual parent of the root
+            const LrlBVHNode& r = s->bvh[0];
+            packed[0] = make_float4(r.bound.min[0], r.bound.min[1], r.bound.min[2], asf(refOf(0)));
+            packed[1] = make_float4(r.bound.max[0], r.bound.max[1], r.bound.max[2], asf(LRL_REF_NONE));
+            packed[2] = make_float4(0, 0, 0, asf(0));
+            packed[3] = make_float4(0, 0, 0, asf(0));
+        }
+        for (uint32_t i = 0; i < N; ++i) {
+            const LrlBVHNode& n = s->bvh[i];
+            if (!n.bound.leftChild) continue;
+            float4* q = &packed[size_t(recOf[i]) * 4];
+            const LrlBVHNode& l = s->bvh[i + 1];
+            uint32_t own = n.geometry ? ((n.geometry << LRL_PRIM_TYPE_SHIFT) | (n.geometryNum & LRL_PRIM_INDEX_MASK)) : 0u;
+            q[0] = make_float4(l.bound.min[0], l.bound.min[1], l.bound.min[2], asf(refOf(i + 1)));
+            if (n.bound.rightChild) {
+                const LrlBVHNode& r = s->bvh[n.bound.rightChild];
+                q[1] = make_float4(l.bound.max[0], l.bound.max[1], l.bound.max[2], asf(refOf(uint32_t(n.bound.rightChild))));
+                q[2] = make_float4(r.bound.min[0], r.bound.min[1], r.bound.min[2], asf(own));
+                q[3] = make_float4(r.bound.max[0], r.bound.max[1], r.bound.max[2], asf(n.axis));
+            } else {
+                q[1] = make_float4(l.bound.max[0], l.bound.max[1], l.bound.max[2], asf(LRL_REF_NONE));
+                q[2] = make_float4(0, 0, 0, asf(own));
+                q[3] = make_float4(0, 0, 0, asf(n.axis));
+            }
         }
         rc = upload(c, c->nodes, packed.data(), packed.size() * sizeof(float4));
         if (rc) return rc;
@@ -322,6 +348,7 @@ int lrl_scene_upload(LrlContext* c, const LrlSceneView* s) {
     } else if ((rc = ensure(c, c->cube, 4))) return rc;
     HIP_TRY(c, hipStreamSynchronize(c->stream));
     c->nodeNum = s->bvhNodeNum;
+    c->recNum = recCount;
     c->bvhDepth = depth;
     c->haveScene = true;
     return LRL_OK;
@@ -393,7 +420,7 @@ int lrl_compute_decay_origin(LrlContext* c, uint32_t variant, LrlDecayOrigin* ou
     if ((rc = ensure(c, c->decayDev, sizeof(LrlDecayOrigin)))) return rc;
     KScene k;
     fillKScene(c, k);
-    HIP_TRY(c, lrl_launch_decay_origin(k, static_cast<const LrlTrans*>(c->transDev.p), c->bvhDepth + 1, variant == LRL_VARIANT_POOL,
+    HIP_TRY(c, lrl_launch_decay_origin(k, static_cast<const LrlTrans*>(c->transDev.p), std::min(c->bvhDepth + 1, LRL_LDS_STACK_ENTRIES), variant == LRL_VARIANT_POOL,
                                        static_cast<LrlDecayOrigin*>(c->decayDev.p), c->stream));
     LrlDecayOrigin h;
     HIP_TRY(c, hipMemcpyAsync(&h, c->decayDev.p, sizeof(h), hipMemcpyDeviceToHost, c->stream));
@@ -436,7 +463,7 @@ static int renderImpl(LrlContext* c, const LrlRenderParams* p, float* rgbaDev, u
     f.rowBegin = p->rowBegin; f.rowEnd = p->rowBegin + rows;
     f.sampleBegin = s0; f.sampleEnd = s1; f.spp = spp;
     f.maxDepth = p->maxDepth;
-    f.stackEntries = c->bvhDepth + 1;
+    f.stackEntries = std::min(c->bvhDepth + 1, LRL_LDS_STACK_ENTRIES);
     hipEvent_t e0 = c->evStart, e1 = c->evStop;
     if (c->timing && c->timingUsed < LRL_MAX_TIMED_LAUNCHES) {
         if (c->timingUsed == c->timingEvents.size()) {
@@ -566,7 +593,7 @@ int lrl_timing_end(LrlContext* c, double* totalMs, uint32_t* launches) {
 
 int lrl_scene_device_bytes(LrlContext* c, uint64_t out[4]) {
     if (!c || !out) return LRL_ERR_INVALID_ARG;
-    out[0] = uint64_t(c->nodeNum) * 32;
+    out[0] = uint64_t(c->recNum) * 64;
     out[1] = uint64_t(c->num.triangleNum) * 64;
     out[2] = uint64_t(c->num.triangleNum) * sizeof(LrlTriCold) + c->materialTable.size() * sizeof(LrlColor);
     out[3] = uint64_t(c->num.sphereNum + c->num.circleNum + c->num.cylinderNum + c->num.coneNum) * 128 + uint64_t(c->num.pointLightNum) * 32 +

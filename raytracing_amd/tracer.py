@@ -12,7 +12,7 @@ import numpy as np
 from . import abi
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "liblrltrace.so")
+LIB_PATH = os.environ.get("LRLTRACE_LIB") or os.path.join(_HERE, "liblrltrace.so")   # env override: kernel-variant experiments only
 _lib = None
 
 EXPORTS = [
