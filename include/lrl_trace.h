@@ -45,8 +45,12 @@ enum LrlStatus {
     LRL_ERR_LIMIT = 6          /* a stated static limit exceeded (depth, spp, scratch) */
 };
 
+#ifndef LRL_MAX_RAY_DEPTH
 #define LRL_MAX_RAY_DEPTH 10u   /* RayTraceDepth, BVH/shaders/RendererFragment0.cpp:2 (Pool: 8) */
+#endif
+#ifndef LRL_MAX_BVH_DEPTH
 #define LRL_MAX_BVH_DEPTH 96u   /* traversal stack entries per lane the kernels can be launched with */
+#endif
 #define LRL_MAX_SPP 4096u
 
 /* Shader variant: the Pool copy of the fragment shader lacks the tex == -2 checkerboard

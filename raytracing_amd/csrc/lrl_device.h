@@ -29,6 +29,11 @@ struct LrlTriCold {
 };
 static_assert(sizeof(LrlTriCold) == 32, "TriCold");
 
+#ifdef LRL_DIAG
+#define LRL_TIMELINE_WORDS 6
+#else
+#define LRL_TIMELINE_WORDS 3
+#endif
 #define LRL_REF_NONE 0xffffffffu
 #define LRL_REF_LEAF 0x80000000u
 #define LRL_PRIM_TYPE_SHIFT 28
@@ -66,13 +71,22 @@ struct KFrame {
     uint32_t spp;                      // divisor of the mean
     uint32_t maxDepth;
     uint32_t stackEntries;             // LDS traversal-stack entries per lane: min(BVH depth + 1, LRL_LDS_STACK_ENTRIES)
+    unsigned long long* timeline;      // diagnostic (env LRL_TIMELINE): per wave {start, end} in 100 MHz ticks + hardware id, else NULL
 };
 
 enum { LRL_CTR_PRIMARY = 0, LRL_CTR_REFLECT, LRL_CTR_REFRACT, LRL_CTR_SHADOW, LRL_CTR_NODES, LRL_CTR_TRI, LRL_CTR_SPH,
        LRL_CTR_OTHER, LRL_CTR_PRIMARY_HITS, LRL_CTR_COUNT };
 
+#ifndef LRL_BLOCK_THREADS
 #define LRL_BLOCK_THREADS 256
+#endif
+#if LRL_BLOCK_THREADS == 256
 #define LRL_TILE 16   // a 256-thread workgroup renders a 16x16 pixel tile, each wave an 8x8 quadrant
+#elif LRL_BLOCK_THREADS == 64
+#define LRL_TILE 8    // one-wave workgroups: an 8x8 tile each
+#else
+#error "LRL_BLOCK_THREADS must be 64 or 256"
+#endif
 
 // kernels_parity.hip / kernels_fast.hip
 hipError_t lrl_launch_render_parity(const KScene& sc, const KFrame& fr, float4* out, uint2* hit, unsigned long long* counters,

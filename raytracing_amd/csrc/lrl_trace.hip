@@ -4,6 +4,8 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <string>
 #include <unordered_map>
@@ -51,7 +53,7 @@ struct LrlContext {
     LrlTrans trans{};
     uint32_t width = 0, height = 0;
     float decayOrigin[4] = {0, 0, 0, 1};
-    DevBuf transDev, outDev, hitDev, counterDev, decayDev;
+    DevBuf transDev, outDev, hitDev, counterDev, decayDev, timelineDev;
     float lastMs = 0;
     bool timed = false;
     bool timing = false;
@@ -212,7 +214,7 @@ int lrl_destroy(LrlContext* c) {
     (void)hipSetDevice(c->device);
     (void)hipStreamSynchronize(c->stream);
     for (DevBuf* b : {&c->nodes, &c->triHot, &c->triCold, &c->materials, &c->spheres, &c->circles, &c->cylinders, &c->cones, &c->lights,
-                      &c->tex, &c->cube, &c->triStage, &c->matStage, &c->transDev, &c->outDev, &c->hitDev, &c->counterDev, &c->decayDev})
+                      &c->tex, &c->cube, &c->triStage, &c->matStage, &c->transDev, &c->outDev, &c->hitDev, &c->counterDev, &c->decayDev, &c->timelineDev})
         release(*b);
     for (auto& e : c->timingEvents) { (void)hipEventDestroy(e.first); (void)hipEventDestroy(e.second); }
     if (c->evStart) (void)hipEventDestroy(c->evStart);
@@ -464,6 +466,16 @@ static int renderImpl(LrlContext* c, const LrlRenderParams* p, float* rgbaDev, u
     f.sampleBegin = s0; f.sampleEnd = s1; f.spp = spp;
     f.maxDepth = p->maxDepth;
     f.stackEntries = std::min(c->bvhDepth + 1, LRL_LDS_STACK_ENTRIES);
+    f.timeline = nullptr;
+    const char* tlPath = std::getenv("LRL_TIMELINE");   // diagnostic: per-wave start/end ticks of this launch, dumped to the named file
+    size_t tlWaves = 0;
+    if (tlPath && *tlPath) {
+        uint32_t tx = (c->width + LRL_TILE - 1) / LRL_TILE, ty = (rows + LRL_TILE - 1) / LRL_TILE;
+        tlWaves = size_t(tx) * ty * (LRL_BLOCK_THREADS / 64);
+        if ((rc = ensure(c, c->timelineDev, tlWaves * 8 * LRL_TIMELINE_WORDS))) return rc;
+        HIP_TRY(c, hipMemsetAsync(c->timelineDev.p, 0, tlWaves * 8 * LRL_TIMELINE_WORDS, stream));
+        f.timeline = static_cast<unsigned long long*>(c->timelineDev.p);
+    }
     hipEvent_t e0 = c->evStart, e1 = c->evStop;
     if (c->timing && c->timingUsed < LRL_MAX_TIMED_LAUNCHES) {
         if (c->timingUsed == c->timingEvents.size()) {
@@ -482,6 +494,12 @@ static int renderImpl(LrlContext* c, const LrlRenderParams* p, float* rgbaDev, u
         HIP_TRY(c, lrl_launch_render_parity(k, f, reinterpret_cast<float4*>(rgbaDev), reinterpret_cast<uint2*>(hitDev), ctr, p->variant == LRL_VARIANT_POOL, stream));
     HIP_TRY(c, hipEventRecord(e1, stream));
     c->timed = (e0 == c->evStart);
+    if (f.timeline) {
+        std::vector<unsigned long long> h(tlWaves * LRL_TIMELINE_WORDS);
+        HIP_TRY(c, hipStreamSynchronize(stream));
+        HIP_TRY(c, hipMemcpy(h.data(), c->timelineDev.p, tlWaves * 8 * LRL_TIMELINE_WORDS, hipMemcpyDeviceToHost));
+        if (FILE* fp = std::fopen(tlPath, "wb")) { std::fwrite(h.data(), 8, h.size(), fp); std::fclose(fp); }
+    }
     return LRL_OK;
 }
 
