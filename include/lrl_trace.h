@@ -65,6 +65,11 @@ enum LrlStatus {
 
 #define LRL_FLAG_COUNTERS 1u      /* accumulate LrlCounters for this render (slower kernel) */
 #define LRL_FLAG_OUT_DEVICE 2u    /* rgba_out / hit_out are device pointers */
+#define LRL_FLAG_MEGAKERNEL 4u    /* one launch, one lane per pixel path (the first design; kept for A/B and as the   */
+                                  /* second schedule of the same arithmetic).  Default: wavefront pipeline, one       */
+                                  /* trace + one shade launch per ray segment                                        */
+#define LRL_FLAG_TIME_KERNELS 8u  /* between lrl_timing_begin/_end: time every trace-kernel launch on its own instead */
+                                  /* of the frame as a whole (adds event records between the launches)               */
 
 typedef struct LrlSceneView {
     /* geometry in the reference's record layouts; counts in `num` */
@@ -138,8 +143,9 @@ int lrl_sync(LrlContext* ctx);
 int lrl_get_counters(LrlContext* ctx, LrlCounters* out);   /* of the last render with LRL_FLAG_COUNTERS */
 /* duration of the trace kernel(s) of the last render, HIP events on the stream they ran on */
 int lrl_last_kernel_ms(LrlContext* ctx, float* ms);
-/* accumulate the trace-kernel durations of every render between _begin and _end (HIP event pairs on the
- * stream each kernel ran on; _end waits for them); at most LRL_MAX_TIMED_LAUNCHES launches are kept */
+/* accumulate device time of every render between _begin and _end (HIP event pairs on the stream the kernels ran
+ * on; _end waits for them): per frame (first to last kernel of the render), or per trace-kernel launch when the
+ * render carries LRL_FLAG_TIME_KERNELS; at most LRL_MAX_TIMED_LAUNCHES pairs are kept */
 #define LRL_MAX_TIMED_LAUNCHES 4096u
 int lrl_timing_begin(LrlContext* ctx);
 int lrl_timing_end(LrlContext* ctx, double* total_ms, uint32_t* launches);

@@ -31,7 +31,7 @@ for _dt, _sz in ((COLOR, 80), (BVHNODE, 64), (TRIANGLE, 160), (TRIANGLE_GPU, 176
 GEOM_TRIANGLE, GEOM_SPHERE, GEOM_CIRCLE, GEOM_CYLINDER, GEOM_CONE = 2, 3, 4, 5, 6
 VARIANT_BVH, VARIANT_POOL = 0, 1
 MODE_PARITY, MODE_FAST = 0, 1
-FLAG_COUNTERS, FLAG_OUT_DEVICE = 1, 2
+FLAG_COUNTERS, FLAG_OUT_DEVICE, FLAG_MEGAKERNEL, FLAG_TIME_KERNELS = 1, 2, 4, 8
 
 
 def color(r=0.0, t=0.0, d=0.0, g=0.0, decay=0.0, n=1.0, texR=-1, texT=-1, texD=-1, texG=-1):

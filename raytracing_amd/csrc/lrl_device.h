@@ -88,6 +88,65 @@ enum { LRL_CTR_PRIMARY = 0, LRL_CTR_REFLECT, LRL_CTR_REFRACT, LRL_CTR_SHADOW, LR
 #error "LRL_BLOCK_THREADS must be 64 or 256"
 #endif
 
+// ---- wavefront form (lrl_wavefront.inc): one kernel launch per ray SEGMENT instead of one lane per pixel path ----
+// Path slots are pixels in 8x8-tile-major order (slot = tile * 64 + y_in_tile * 8 + x_in_tile), so 64 consecutive
+// slots are one wave's tile.  Ray index space: [0, P) = the closest-hit ray of slot r; [P * (1 + li) + slot] = the
+// shadow ray of that slot towards light li.  A ray exists when its bit is set in maskC / maskS (one 64-bit word
+// per 64 slots, written whole by one wave of the shade kernel: no atomics, no compaction, fixed addresses).
+#ifndef LRL_WF_CHUNK_WORDS
+#define LRL_WF_CHUNK_WORDS 4u     /* mask words (64 ray slots each) per one-wave trace workgroup: <= 4 rays per lane */
+#endif
+#ifndef LRL_WF_STACK
+#define LRL_WF_STACK 10           /* pending-far-child entries per lane in LDS; deeper ones go to WFrame::overflow */
+#endif
+#ifndef LRL_WF_TRACE_WAVES
+#define LRL_WF_TRACE_WAVES 8      /* __launch_bounds__ waves per SIMD of the trace kernel */
+#endif
+#define LRL_WF_SLOT_ALIGN (64u * LRL_WF_CHUNK_WORDS > 256u ? 64u * LRL_WF_CHUNK_WORDS : 256u)
+
+#define LRL_WF_ALIVE 1u       /* path not finished */
+#define LRL_WF_HASRAY 2u      /* a closest-hit ray of this path was traced in this iteration */
+#define LRL_WF_PENDING 4u     /* shadow rays of the previous segment were traced: add their light now */
+#define LRL_WF_FIRST 8u       /* the segment in flight is the primary ray */
+#define LRL_WF_DEPTH_SHIFT 8  /* 4 bits: depth */
+#define LRL_WF_SP_SHIFT 12    /* 4 bits: refraction stack entries */
+
+struct WFrame {
+    uint32_t P;              // path slots, multiple of LRL_WF_SLOT_ALIGN
+    uint32_t words;          // P / 64
+    uint32_t tilesX;         // 8x8 tiles per row of tiles
+    uint32_t sample;         // sample index rendered by this pass
+    uint32_t overflowEntries;   // per-lane entries of `overflow` (0: the LDS stack always suffices)
+    float4* answer;          // xyz accumulated colour, w = v of the pending light terms
+    float4* ratio;           // ratioNow
+    float4* decay;           // decayNow
+    float4* rayO;            // ray of the segment in flight (origin, direction)
+    float4* rayD;
+    float4* hit;             // closest-hit result of the segment in flight: t, primitive bits, aux
+    float4* pendA;           // pending light terms: diffuse colour, texD
+    float4* pendB;           //                      ratio at the hit, u
+    uint32_t* flags;
+    float4* rayQ;            // 2 float4 per ray: {origin, tmax (-1: closest-hit)} {direction, k (shadow: light factor; set to -1 when occluded)}
+    unsigned long long* maskC;
+    unsigned long long* maskS;
+    float4* refr;            // refraction stack [entry][4][P], NULL when no material transmits
+    uint2* overflow;         // [trace workgroup][overflowEntries][64]
+    uint32_t* alive;         // [iteration]: set to 1 by the shade kernel while any path is unfinished
+    float4* out;
+    uint2* hitOut;
+    unsigned long long* counters;
+    unsigned long long* timeline;   // diagnostic (env LRL_TIMELINE): per trace workgroup {start, end, hw id, max trips of one ray, sum of trips, wave trips}
+};
+
+#define LRL_WF_DECLARE(ns)                                                                                            \
+    namespace ns {                                                                                                    \
+    hipError_t wfLaunchGenerate(const KScene& sc, const KFrame& fr, const WFrame& wf, hipStream_t stream);            \
+    hipError_t wfLaunchTrace(const KScene& sc, const WFrame& wf, hipStream_t stream);                                 \
+    hipError_t wfLaunchShade(const KScene& sc, const KFrame& fr, const WFrame& wf, uint32_t iter, bool pool, hipStream_t stream); \
+    }
+LRL_WF_DECLARE(lrl_parity)
+LRL_WF_DECLARE(lrl_fast)
+
 // kernels_parity.hip / kernels_fast.hip
 hipError_t lrl_launch_render_parity(const KScene& sc, const KFrame& fr, float4* out, uint2* hit, unsigned long long* counters,
                                     bool pool, hipStream_t stream);

@@ -54,6 +54,11 @@ struct LrlContext {
     uint32_t width = 0, height = 0;
     float decayOrigin[4] = {0, 0, 0, 1};
     DevBuf transDev, outDev, hitDev, counterDev, decayDev, timelineDev;
+    DevBuf wfArena;                     // wavefront pipeline: path state, ray records, masks, refraction stacks, overflow stacks
+    uint32_t* aliveHost = nullptr;      // pinned: per-iteration "any path alive" words copied back while the next iteration runs
+    hipEvent_t evIter[2] = {nullptr, nullptr};
+    bool hasTransmission = false;       // some material has t != 0: refraction stacks are needed
+    uint32_t lastIterations = 0;
     float lastMs = 0;
     bool timed = false;
     bool timing = false;
@@ -91,7 +96,10 @@ int upload(LrlContext* c, DevBuf& b, const void* src, size_t bytes) {
 }
 void release(DevBuf& b) { if (b.p) { (void)hipFree(b.p); b.p = nullptr; b.bytes = 0; } }
 
+bool transmits(const LrlColor& col) { return !(col.t[0] == 0.0f && col.t[1] == 0.0f && col.t[2] == 0.0f); }   // NaN counts as transmitting
+
 uint32_t internMaterial(LrlContext* c, const LrlColor& col) {
+    if (transmits(col)) c->hasTransmission = true;
     ColorKey k;
     std::memcpy(k.w, &col, sizeof(k.w));
     auto it = c->materialIndex.find(k);
@@ -214,9 +222,11 @@ int lrl_destroy(LrlContext* c) {
     (void)hipSetDevice(c->device);
     (void)hipStreamSynchronize(c->stream);
     for (DevBuf* b : {&c->nodes, &c->triHot, &c->triCold, &c->materials, &c->spheres, &c->circles, &c->cylinders, &c->cones, &c->lights,
-                      &c->tex, &c->cube, &c->triStage, &c->matStage, &c->transDev, &c->outDev, &c->hitDev, &c->counterDev, &c->decayDev, &c->timelineDev})
+                      &c->tex, &c->cube, &c->triStage, &c->matStage, &c->transDev, &c->outDev, &c->hitDev, &c->counterDev, &c->decayDev, &c->timelineDev, &c->wfArena})
         release(*b);
     for (auto& e : c->timingEvents) { (void)hipEventDestroy(e.first); (void)hipEventDestroy(e.second); }
+    if (c->aliveHost) (void)hipHostFree(c->aliveHost);
+    for (hipEvent_t e : c->evIter) if (e) (void)hipEventDestroy(e);
     if (c->evStart) (void)hipEventDestroy(c->evStart);
     if (c->evStop) (void)hipEventDestroy(c->evStop);
     if (c->stream) (void)hipStreamDestroy(c->stream);
@@ -285,6 +295,11 @@ int lrl_scene_upload(LrlContext* c, const LrlSceneView* s) {
     }
     c->materialTable.clear();
     c->materialIndex.clear();
+    c->hasTransmission = false;
+    for (uint32_t i = 0; i < g.sphereNum; ++i) if (transmits(s->spheres[i].color)) c->hasTransmission = true;
+    for (uint32_t i = 0; i < g.circleNum; ++i) if (transmits(s->circles[i].color)) c->hasTransmission = true;
+    for (uint32_t i = 0; i < g.cylinderNum; ++i) if (transmits(s->cylinders[i].color)) c->hasTransmission = true;
+    for (uint32_t i = 0; i < g.coneNum; ++i) if (transmits(s->cones[i].color)) c->hasTransmission = true;
     rc = ensure(c, c->triHot, size_t(g.triangleNum) * 64);
     if (rc) return rc;
     rc = ensure(c, c->triCold, size_t(g.triangleNum) * sizeof(LrlTriCold));
@@ -432,6 +447,111 @@ int lrl_compute_decay_origin(LrlContext* c, uint32_t variant, LrlDecayOrigin* ou
     return LRL_OK;
 }
 
+
+// ---- wavefront pipeline: generate, then (trace, shade) per ray segment until no path is alive ----
+#define LRL_WF_MAX_ITERATIONS 4096u
+static int renderWavefront(LrlContext* c, const LrlRenderParams* p, const KScene& k, KFrame f, float* rgbaDev, uint32_t* hitDev,
+                           unsigned long long* ctr, hipStream_t stream, uint32_t rows, hipEvent_t e0, hipEvent_t e1) {
+    const bool fast = p->mode == LRL_MODE_FAST, pool = p->variant == LRL_VARIANT_POOL;
+    const uint32_t L = c->num.pointLightNum;
+    const uint32_t tilesX = (c->width + 7) / 8, tilesY = (rows + 7) / 8;
+    const uint64_t P64 = (uint64_t(tilesX) * tilesY * 64 + LRL_WF_SLOT_ALIGN - 1) / LRL_WF_SLOT_ALIGN * LRL_WF_SLOT_ALIGN;
+    if (P64 * (1 + uint64_t(L)) >= (1ull << 31)) return fail(c, LRL_ERR_LIMIT, "pixels x (1 + lights) of one render exceeds 2^31 ray slots: render in row stripes");
+    const size_t P = size_t(P64);
+    const uint32_t words = uint32_t(P / 64), chunks = words * (1 + L) / LRL_WF_CHUNK_WORDS;
+    const uint32_t ovf = c->bvhDepth + 1 > uint32_t(LRL_WF_STACK) ? c->bvhDepth + 1 - uint32_t(LRL_WF_STACK) : 0u;
+    const uint32_t refrEntries = c->hasTransmission ? p->maxDepth : 0u;
+    // arena layout (every block 256-B aligned)
+    size_t off = 0;
+    auto take = [&](size_t bytes) { size_t o = off; off += (bytes + 255) / 256 * 256; return o; };
+    const size_t oState = take(P * 16 * 8), oFlags = take(P * 4), oRayQ = take(P * (1 + size_t(L)) * 32), oMaskC = take(size_t(words) * 8),
+                 oMaskS = take(size_t(words) * 8), oRefr = take(P * 64 * refrEntries), oOvf = take(size_t(chunks) * ovf * 512),
+                 oAlive = take(LRL_WF_MAX_ITERATIONS * 4);
+    int rc = ensure(c, c->wfArena, off);
+    if (rc) return rc;
+    if (!c->aliveHost) {
+        HIP_TRY(c, hipHostMalloc(reinterpret_cast<void**>(&c->aliveHost), LRL_WF_MAX_ITERATIONS * 4, hipHostMallocDefault));
+        HIP_TRY(c, hipEventCreateWithFlags(&c->evIter[0], hipEventDisableTiming));
+        HIP_TRY(c, hipEventCreateWithFlags(&c->evIter[1], hipEventDisableTiming));
+    }
+    char* base = static_cast<char*>(c->wfArena.p);
+    WFrame wf{};
+    wf.P = uint32_t(P); wf.words = words; wf.tilesX = tilesX; wf.overflowEntries = ovf;
+    float4* st = reinterpret_cast<float4*>(base + oState);
+    wf.answer = st; wf.ratio = st + P; wf.decay = st + 2 * P; wf.rayO = st + 3 * P; wf.rayD = st + 4 * P; wf.hit = st + 5 * P;
+    wf.pendA = st + 6 * P; wf.pendB = st + 7 * P;
+    wf.flags = reinterpret_cast<uint32_t*>(base + oFlags);
+    wf.rayQ = reinterpret_cast<float4*>(base + oRayQ);
+    wf.maskC = reinterpret_cast<unsigned long long*>(base + oMaskC);
+    wf.maskS = reinterpret_cast<unsigned long long*>(base + oMaskS);
+    wf.refr = refrEntries ? reinterpret_cast<float4*>(base + oRefr) : nullptr;
+    wf.overflow = reinterpret_cast<uint2*>(base + oOvf);
+    wf.alive = reinterpret_cast<uint32_t*>(base + oAlive);
+    wf.out = reinterpret_cast<float4*>(rgbaDev);
+    wf.hitOut = reinterpret_cast<uint2*>(hitDev);
+    wf.counters = ctr;
+    wf.timeline = nullptr;
+    const char* tlPath = std::getenv("LRL_TIMELINE");          // diagnostic builds (LRL_DIAG): timeline of ONE trace launch
+    const char* tlIter = std::getenv("LRL_TIMELINE_ITER");
+    const uint32_t tlWanted = tlIter ? uint32_t(std::atoi(tlIter)) : 0u;
+    if (tlPath && *tlPath && (rc = ensure(c, c->timelineDev, size_t(chunks) * 48))) return rc;
+    // every path ends after at most 2^(maxDepth+1) segments (each hit continues one reflection and parks one refraction)
+    const uint32_t bound = std::min<uint64_t>(LRL_WF_MAX_ITERATIONS, (2ull << p->maxDepth) + 2);
+    const bool perKernel = c->timing && (p->flags & LRL_FLAG_TIME_KERNELS);
+    auto timedTrace = [&]() -> int {
+        hipEvent_t a = nullptr, b = nullptr;
+        if (perKernel && c->timingUsed < LRL_MAX_TIMED_LAUNCHES) {
+            if (c->timingUsed == c->timingEvents.size()) {
+                HIP_TRY(c, hipEventCreate(&a));
+                HIP_TRY(c, hipEventCreate(&b));
+                c->timingEvents.emplace_back(a, b);
+            }
+            a = c->timingEvents[c->timingUsed].first; b = c->timingEvents[c->timingUsed].second;
+            ++c->timingUsed;
+            HIP_TRY(c, hipEventRecord(a, stream));
+        }
+        HIP_TRY(c, fast ? lrl_fast::wfLaunchTrace(k, wf, stream) : lrl_parity::wfLaunchTrace(k, wf, stream));
+        if (b) HIP_TRY(c, hipEventRecord(b, stream));
+        return LRL_OK;
+    };
+    auto dumpTimeline = [&]() -> int {
+        std::vector<unsigned long long> h(size_t(chunks) * 6);
+        HIP_TRY(c, hipStreamSynchronize(stream));
+        HIP_TRY(c, hipMemcpy(h.data(), c->timelineDev.p, h.size() * 8, hipMemcpyDeviceToHost));
+        if (FILE* fp = std::fopen(tlPath, "wb")) { std::fwrite(h.data(), 8, h.size(), fp); std::fclose(fp); }
+        return LRL_OK;
+    };
+    if (e0) HIP_TRY(c, hipEventRecord(e0, stream));
+    uint32_t iterations = 0;
+    for (uint32_t s = f.sampleBegin; s < f.sampleEnd; ++s) {
+        wf.sample = s;
+        HIP_TRY(c, hipMemsetAsync(wf.alive, 0, size_t(bound) * 4, stream));
+        HIP_TRY(c, fast ? lrl_fast::wfLaunchGenerate(k, f, wf, stream) : lrl_parity::wfLaunchGenerate(k, f, wf, stream));
+        uint32_t iter = 0;
+        for (; iter < bound; ++iter) {
+            const bool tl = tlPath && *tlPath && iter == tlWanted && s == f.sampleBegin;
+            if (tl) { HIP_TRY(c, hipMemsetAsync(c->timelineDev.p, 0, size_t(chunks) * 48, stream)); wf.timeline = static_cast<unsigned long long*>(c->timelineDev.p); }
+            if ((rc = timedTrace())) return rc;
+            if (tl) { wf.timeline = nullptr; if ((rc = dumpTimeline())) return rc; }
+            HIP_TRY(c, fast ? lrl_fast::wfLaunchShade(k, f, wf, iter, pool, stream) : lrl_parity::wfLaunchShade(k, f, wf, iter, pool, stream));
+            HIP_TRY(c, hipMemcpyAsync(c->aliveHost + iter, wf.alive + iter, 4, hipMemcpyDeviceToHost, stream));
+            HIP_TRY(c, hipEventRecord(c->evIter[iter & 1], stream));
+            if (iter >= 1) {      // look at the iteration before while this one runs: the pipeline ends one (empty) iteration late
+                HIP_TRY(c, hipEventSynchronize(c->evIter[(iter - 1) & 1]));
+                if (c->aliveHost[iter - 1] == 0) { ++iter; break; }
+            }
+        }
+        if (iter == bound) {      // the last iteration has not been looked at yet
+            HIP_TRY(c, hipEventSynchronize(c->evIter[(bound - 1) & 1]));
+            if (c->aliveHost[bound - 1] != 0) return fail(c, LRL_ERR_LIMIT, "wavefront pipeline did not finish within its iteration bound");
+        }
+        iterations += iter;
+    }
+    if (e1) HIP_TRY(c, hipEventRecord(e1, stream));
+    c->lastIterations = iterations;
+    return LRL_OK;
+}
+
 static int renderImpl(LrlContext* c, const LrlRenderParams* p, float* rgbaDev, uint32_t* hitDev, hipStream_t stream, uint32_t rows) {
     const uint32_t spp = p->spp;
     uint32_t s0 = p->sampleBegin, s1 = p->sampleEnd;
@@ -476,8 +596,10 @@ static int renderImpl(LrlContext* c, const LrlRenderParams* p, float* rgbaDev, u
         HIP_TRY(c, hipMemsetAsync(c->timelineDev.p, 0, tlWaves * 8 * LRL_TIMELINE_WORDS, stream));
         f.timeline = static_cast<unsigned long long*>(c->timelineDev.p);
     }
+    const bool mega = (p->flags & LRL_FLAG_MEGAKERNEL) != 0;
+    const bool perKernel = !mega && c->timing && (p->flags & LRL_FLAG_TIME_KERNELS);
     hipEvent_t e0 = c->evStart, e1 = c->evStop;
-    if (c->timing && c->timingUsed < LRL_MAX_TIMED_LAUNCHES) {
+    if (c->timing && !perKernel && c->timingUsed < LRL_MAX_TIMED_LAUNCHES) {
         if (c->timingUsed == c->timingEvents.size()) {
             hipEvent_t a, b;
             HIP_TRY(c, hipEventCreate(&a));
@@ -486,6 +608,11 @@ static int renderImpl(LrlContext* c, const LrlRenderParams* p, float* rgbaDev, u
         }
         e0 = c->timingEvents[c->timingUsed].first; e1 = c->timingEvents[c->timingUsed].second;
         ++c->timingUsed;
+    }
+    if (!mega) {
+        if ((rc = renderWavefront(c, p, k, f, rgbaDev, hitDev, ctr, stream, rows, e0, e1))) return rc;
+        c->timed = (e0 == c->evStart);
+        return LRL_OK;
     }
     HIP_TRY(c, hipEventRecord(e0, stream));
     if (p->mode == LRL_MODE_FAST)

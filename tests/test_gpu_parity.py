@@ -266,3 +266,21 @@ def test_full_size_properties_1080p(tracer, bunny0_model):
     oimg, ohits, _ = O.render(m.scene_view(), tr, W, H, max_depth=4, rows=(512, 560), threads=8)
     assert (hits[512:560] == ohits).all(axis=-1).mean() >= ID_BAR
     assert image_stats(stripe, oimg)["rmse"] <= RMSE_PARITY
+
+
+@pytest.mark.parametrize("name", ["bvh_viewB_256", "bvh_viewB_128_spp4", "bvh_inside_glass_128"])
+def test_wavefront_and_megakernel_schedules_agree_bit_for_bit(tracer, default_model, name):
+    """The wavefront pipeline (default) and the one-launch kernel run the same PARITY arithmetic in a different order of
+    launches: images, primary ids and every counter must be identical, glass (refraction stacks) and spp included."""
+    g = load_golden(name)
+    tracer.scene_upload(default_model.scene_view())
+    tracer.set_camera(g["trans"], g["width"], g["height"])
+    tracer.set_decay_origin(g["decay"].reshape(9, 4)[8] if name == "bvh_inside_glass_128" else (0, 0, 0, 1))
+    jitter = g["jitter"] if "jitter" in g else None
+    out = {}
+    for mega in (False, True):
+        img, hits = tracer.render(max_depth=g["depth"], mode=abi.MODE_PARITY, jitter=jitter, counters=True, megakernel=mega)
+        out[mega] = (img, hits, tracer.counters().as_dict())
+    assert np.array_equal(out[False][0].view(np.uint32), out[True][0].view(np.uint32))
+    assert np.array_equal(out[False][1], out[True][1])
+    assert out[False][2] == out[True][2]

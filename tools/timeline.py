@@ -28,7 +28,7 @@ u = np.unique(ids)
 print(f"distinct (xcc,se,sh,cu) ids seen: {len(u)}; xcc histogram {np.bincount(xcc.astype(int))}")
 if words >= 6:
     mx, sm, it = a[:, 3].astype(np.float64), a[:, 4].astype(np.float64), a[:, 5].astype(np.float64)
-    print(f"record fetches per lane-path: chip max {mx.max():.0f}; per wave: loop trips mean {it.mean():.0f} max {it.max():.0f}; lane efficiency sum/(64*trips) {sm.sum()/(64*it.sum()):.3f}")
+    print(f"trips of one lane-path/ray: chip max {mx.max():.0f}; per wave: loop trips mean {it.mean():.0f} max {it.max():.0f}; lane efficiency sum/(64*trips) {sm.sum()/(64*it.sum()):.3f}")
     k = np.argsort(-d)[:8]
     for i in k: print(f"   wave {i}: {d[i]:.0f} us, trips {it[i]:.0f}, max lane steps {mx[i]:.0f}, sum {sm[i]:.0f}  -> {d[i]*1e3/max(it[i],1):.0f} ns/trip")
     print(f"all waves: ns per loop trip {d.sum()*1e3/it.sum():.0f}")
