@@ -47,6 +47,7 @@ static_assert(sizeof(LrlTriCold) == 32, "TriCold");
 
 struct KScene {
     const float4* recs;
+    const float4* wide;      // 4-wide repack (lrl_wide.inc): 16 float4 per node
     const float4* triHot;
     const LrlTriCold* triCold;
     const LrlColor* materials;
@@ -94,13 +95,19 @@ enum { LRL_CTR_PRIMARY = 0, LRL_CTR_REFLECT, LRL_CTR_REFRACT, LRL_CTR_SHADOW, LR
 // shadow ray of that slot towards light li.  A ray exists when its bit is set in maskC / maskS (one 64-bit word
 // per 64 slots, written whole by one wave of the shade kernel: no atomics, no compaction, fixed addresses).
 #ifndef LRL_WF_CHUNK_WORDS
-#define LRL_WF_CHUNK_WORDS 4u     /* mask words (64 ray slots each) per one-wave trace workgroup: <= 4 rays per lane */
+#define LRL_WF_CHUNK_WORDS 1u     /* mask words (64 ray slots each) per one-wave trace workgroup: <= 4 rays per lane */
 #endif
 #ifndef LRL_WF_STACK
 #define LRL_WF_STACK 10           /* pending-far-child entries per lane in LDS; deeper ones go to WFrame::overflow */
 #endif
 #ifndef LRL_WF_TRACE_WAVES
 #define LRL_WF_TRACE_WAVES 8      /* __launch_bounds__ waves per SIMD of the trace kernel */
+#endif
+#ifndef LRL_WF_LEAN_WAVES
+#define LRL_WF_LEAN_WAVES 6       /* __launch_bounds__ waves per SIMD of the lean trace kernel */
+#endif
+#ifndef LRL_W4_STACK
+#define LRL_W4_STACK 24           /* stack entries per QUAD in LDS of the 4-wide trace kernel */
 #endif
 #define LRL_WF_SLOT_ALIGN (64u * LRL_WF_CHUNK_WORDS > 256u ? 64u * LRL_WF_CHUNK_WORDS : 256u)
 
@@ -146,6 +153,11 @@ struct WFrame {
     }
 LRL_WF_DECLARE(lrl_parity)
 LRL_WF_DECLARE(lrl_fast)
+namespace lrl_fast {
+hipError_t wfLaunchTraceWide(const KScene& sc, const WFrame& wf, uint32_t raysPerQuad, hipStream_t stream);
+hipError_t wfLaunchTraceLean(const KScene& sc, const WFrame& wf, hipStream_t stream);
+hipError_t wfLaunchWideFill(float4* wide, const float4* triHot, uint32_t slots, hipStream_t stream);
+}
 
 // kernels_parity.hip / kernels_fast.hip
 hipError_t lrl_launch_render_parity(const KScene& sc, const KFrame& fr, float4* out, uint2* hit, unsigned long long* counters,
