@@ -106,6 +106,12 @@ enum { LRL_CTR_PRIMARY = 0, LRL_CTR_REFLECT, LRL_CTR_REFRACT, LRL_CTR_SHADOW, LR
 #ifndef LRL_WF_LEAN_WAVES
 #define LRL_WF_LEAN_WAVES 6       /* __launch_bounds__ waves per SIMD of the lean trace kernel */
 #endif
+#ifndef LRL_W4_WAVES
+#define LRL_W4_WAVES 6            /* __launch_bounds__ waves per SIMD of the 4-wide trace kernel */
+#endif
+#ifndef LRL_SWARM_CAP
+#define LRL_SWARM_CAP 1024         /* frontier entries of the wave-per-ray continuation kernel (LDS) */
+#endif
 #ifndef LRL_W4_STACK
 #define LRL_W4_STACK 24           /* stack entries per QUAD in LDS of the 4-wide trace kernel */
 #endif
@@ -139,6 +145,14 @@ struct WFrame {
     float4* refr;            // refraction stack [entry][4][P], NULL when no material transmits
     uint2* overflow;         // [trace workgroup][overflowEntries][64]
     uint32_t* alive;         // [iteration]: set to 1 by the shade kernel while any path is unfinished
+    // hand-over of long chains (lrl_lean.inc -> wfTraceSwarmKernel): a ray still going after `handoverTrips` trips leaves
+    // its pending work here and a whole wave finishes it
+    uint32_t handoverTrips;  // 0: never hand over
+    uint32_t contSlots;      // capacity of contHead / contRefs
+    uint32_t contStride;     // refs per slot (>= deepest stack + 1)
+    uint32_t* contCount;     // slots taken by this launch (zero before it)
+    uint4* contHead;         // {ray index, tFar bits (ray.t, < 0: nothing hit), hit primitive, number of refs}
+    uint32_t* contRefs;      // [slot][contStride]
     float4* out;
     uint2* hitOut;
     unsigned long long* counters;
@@ -156,6 +170,7 @@ LRL_WF_DECLARE(lrl_fast)
 namespace lrl_fast {
 hipError_t wfLaunchTraceWide(const KScene& sc, const WFrame& wf, uint32_t raysPerQuad, hipStream_t stream);
 hipError_t wfLaunchTraceLean(const KScene& sc, const WFrame& wf, hipStream_t stream);
+hipError_t wfLaunchTraceSwarm(const KScene& sc, const WFrame& wf, hipStream_t stream);
 hipError_t wfLaunchWideFill(float4* wide, const float4* triHot, uint32_t slots, hipStream_t stream);
 }
 

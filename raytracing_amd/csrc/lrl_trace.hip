@@ -556,13 +556,13 @@ static int renderWavefront(LrlContext* c, const LrlRenderParams* p, const KScene
     const uint32_t words = uint32_t(P / 64), chunks = words * (1 + L) / LRL_WF_CHUNK_WORDS;
     // FAST renders without counters trace the 4-wide repack with a quad per ray; PARITY and counting renders keep the reference's visit order
     // Trace kernel per iteration.  PARITY and counting renders: wfTraceKernel (the reference's visit order).  FAST: the lean
-    // one-lane-per-ray kernel while launches are dominated by their number of rays (the first iterations), then the
-    // 4-wide kernel with a quad per ray, where a launch is a few long chains.  LRL_TRACE / LRL_HYBRID_ITER: experiments.
-    const char* which = std::getenv("LRL_TRACE");      // "ref" | "lean" | "wide" | "wide1" | "hybrid" (default)
+    // one-lane-per-ray kernel, which hands rays that are still going after handoverTrips trips to the wave-per-ray kernel.
+    // LRL_TRACE / LRL_HYBRID_ITER / LRL_HANDOVER*: experiments (the 4-wide quad-per-ray kernel among them).
+    const char* which = std::getenv("LRL_TRACE");      // "ref" | "lean" (default) | "wide" | "wide1" | "hybrid"
     const char* hyb = std::getenv("LRL_HYBRID_ITER");
     const bool special = fast && !ctr && !(which && !std::strcmp(which, "ref"));
-    uint32_t leanIters = hyb ? uint32_t(std::atoi(hyb)) : 2u, wideR = 1;
-    if (special && which && !std::strcmp(which, "lean")) leanIters = 0xffffffffu;
+    uint32_t leanIters = 0xffffffffu, wideR = 1;
+    if (special && which && !std::strcmp(which, "hybrid")) leanIters = hyb ? uint32_t(std::atoi(hyb)) : 2u;
     if (special && which && !std::strcmp(which, "wide")) { leanIters = 0; wideR = 4; }
     if (special && which && !std::strcmp(which, "wide1")) leanIters = 0;
     const uint32_t wideNeed = 3 * c->wideDepth + 4;
@@ -576,7 +576,9 @@ static int renderWavefront(LrlContext* c, const LrlRenderParams* p, const KScene
     auto take = [&](size_t bytes) { size_t o = off; off += (bytes + 255) / 256 * 256; return o; };
     const size_t oState = take(P * 16 * 8), oFlags = take(P * 4), oRayQ = take(P * (1 + size_t(L)) * 32), oMaskC = take(size_t(words) * 8),
                  oMaskS = take(size_t(words) * 8), oRefr = take(P * 64 * refrEntries), oOvf = take(ovfBytes),
-                 oAlive = take(LRL_WF_MAX_ITERATIONS * 4);
+                 oAlive = take(LRL_WF_MAX_ITERATIONS * 4 * 2);
+    const uint32_t contSlots = 65536, contStride = c->bvhDepth + 2;
+    const size_t oContHead = take(size_t(contSlots) * 16), oContRefs = take(size_t(contSlots) * contStride * 4);
     int rc = ensure(c, c->wfArena, off);
     if (rc) return rc;
     if (!c->aliveHost) {
@@ -597,6 +599,15 @@ static int renderWavefront(LrlContext* c, const LrlRenderParams* p, const KScene
     wf.refr = refrEntries ? reinterpret_cast<float4*>(base + oRefr) : nullptr;
     wf.overflow = reinterpret_cast<uint2*>(base + oOvf);
     wf.alive = reinterpret_cast<uint32_t*>(base + oAlive);
+    uint32_t* const contCounts = wf.alive + LRL_WF_MAX_ITERATIONS;      // one per iteration, zeroed with `alive`
+    const char* ho = std::getenv("LRL_HANDOVER");
+    const char* hoLate = std::getenv("LRL_HANDOVER_LATE");
+    const uint32_t handoverEarly = ho ? uint32_t(std::atoi(ho)) : 128u, handoverLate = hoLate ? uint32_t(std::atoi(hoLate)) : 64u;
+    wf.handoverTrips = handoverEarly;
+    wf.contSlots = contSlots; wf.contStride = contStride;
+    wf.contHead = reinterpret_cast<uint4*>(base + oContHead);
+    wf.contRefs = reinterpret_cast<uint32_t*>(base + oContRefs);
+    wf.contCount = contCounts;
     wf.out = reinterpret_cast<float4*>(rgbaDev);
     wf.hitOut = reinterpret_cast<uint2*>(hitDev);
     wf.counters = ctr;
@@ -606,7 +617,9 @@ static int renderWavefront(LrlContext* c, const LrlRenderParams* p, const KScene
     const uint32_t tlWanted = tlIter ? uint32_t(std::atoi(tlIter)) : 0u;
     if (tlPath && *tlPath && (rc = ensure(c, c->timelineDev, (raysAll / 16) * 48))) return rc;
     // every path ends after at most 2^(maxDepth+1) segments (each hit continues one reflection and parks one refraction)
-    const uint32_t bound = std::min<uint64_t>(LRL_WF_MAX_ITERATIONS, (2ull << p->maxDepth) + 2);
+    // (without a transmitting material nothing is ever parked: a path is primary + at most maxDepth reflections, and its
+    // last segment casts no shadow rays, so iteration maxDepth finalises whatever is left)
+    const uint32_t bound = c->hasTransmission ? uint32_t(std::min<uint64_t>(LRL_WF_MAX_ITERATIONS, (2ull << p->maxDepth) + 2)) : p->maxDepth + 1;
     const bool perKernel = c->timing && (p->flags & LRL_FLAG_TIME_KERNELS);
     auto timedTrace = [&](uint32_t iter) -> int {
         hipEvent_t a = nullptr, b = nullptr;
@@ -624,7 +637,12 @@ static int renderWavefront(LrlContext* c, const LrlRenderParams* p, const KScene
             WFrame w4 = wf;
             w4.overflowEntries = ovfW;
             HIP_TRY(c, lrl_fast::wfLaunchTraceWide(k, w4, wideR, stream));
-        } else if (special) HIP_TRY(c, lrl_fast::wfLaunchTraceLean(k, wf, stream));
+        } else if (special) {
+            wf.contCount = contCounts + (iter < LRL_WF_MAX_ITERATIONS ? iter : 0);
+            wf.handoverTrips = iter < 2 ? handoverEarly : handoverLate;   // few rays left after the first bounces: the waves are free sooner
+            HIP_TRY(c, lrl_fast::wfLaunchTraceLean(k, wf, stream));
+            if (wf.handoverTrips) HIP_TRY(c, lrl_fast::wfLaunchTraceSwarm(k, wf, stream));
+        }
         else HIP_TRY(c, fast ? lrl_fast::wfLaunchTrace(k, wf, stream) : lrl_parity::wfLaunchTrace(k, wf, stream));
         if (b) HIP_TRY(c, hipEventRecord(b, stream));
         return LRL_OK;
@@ -640,7 +658,7 @@ static int renderWavefront(LrlContext* c, const LrlRenderParams* p, const KScene
     uint32_t iterations = 0;
     for (uint32_t s = f.sampleBegin; s < f.sampleEnd; ++s) {
         wf.sample = s;
-        HIP_TRY(c, hipMemsetAsync(wf.alive, 0, size_t(bound) * 4, stream));
+        HIP_TRY(c, hipMemsetAsync(wf.alive, 0, size_t(LRL_WF_MAX_ITERATIONS) * 4 + size_t(bound) * 4, stream));
         HIP_TRY(c, fast ? lrl_fast::wfLaunchGenerate(k, f, wf, stream) : lrl_parity::wfLaunchGenerate(k, f, wf, stream));
         uint32_t iter = 0;
         for (; iter < bound; ++iter) {
@@ -661,6 +679,14 @@ static int renderWavefront(LrlContext* c, const LrlRenderParams* p, const KScene
             if (c->aliveHost[bound - 1] != 0) return fail(c, LRL_ERR_LIMIT, "wavefront pipeline did not finish within its iteration bound");
         }
         iterations += iter;
+        if (std::getenv("LRL_DEBUG") && special) {
+            std::vector<uint32_t> cc(iter);
+            HIP_TRY(c, hipStreamSynchronize(stream));
+            HIP_TRY(c, hipMemcpy(cc.data(), contCounts, iter * 4, hipMemcpyDeviceToHost));
+            std::fprintf(stderr, "lrl: handed-over rays per iteration (threshold %u):", wf.handoverTrips);
+            for (uint32_t v : cc) std::fprintf(stderr, " %u", v);
+            std::fprintf(stderr, "\n");
+        }
     }
     if (e1) HIP_TRY(c, hipEventRecord(e1, stream));
     c->lastIterations = iterations;
