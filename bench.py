@@ -3,10 +3,15 @@
 
 Workload (BASELINE.json configs[1]): Stanford bunny x 2 midpoint subdivisions
 (1 240 960 triangles) + ground disc + 1 point light, 1920x1080, 1 spp, 4 bounces.  A "step" is one
-frame: one launch of the trace kernel over every pixel, scene and camera already resident in HBM,
-image written to HBM.  rays = primary + reflection + refraction + shadow segments (device counters,
-taken by an un-timed launch of the counting variant of the same kernel and checked against the CPU
-oracle in tests/).
+frame: the wavefront pipeline (generate, then trace + shade per ray segment) over every pixel, scene
+and camera already resident in HBM, image written to HBM.  rays = primary + reflection + refraction
++ shadow segments (device counters of an un-timed counting render, which walks the tree in the
+reference's order; checked against the CPU oracle in tests/).
+
+Roofline: the dominant kernels are the trace kernels (one launch per ray segment: 5 per frame here).
+achieved = algorithmic bytes of one frame / device time of that frame's trace launches, timed with
+HIP events around every trace launch in a separate short pass (the event records add gaps, so that
+pass is not the one `value` comes from).  frame_ms is the device time of the whole pipeline.
 
 N > 1 (torchrun, one rank per GPU): the scene is replicated; every rank renders the whole frame for
 ONE sample of an N-sample jitter table (sample-index sharding, so per-GPU work is fixed: weak
@@ -109,7 +114,15 @@ def main():
         dist.barrier()
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
-    kernel_ms_total, launches = tr.timing_end()
+    frame_ms_total, frames = tr.timing_end()
+
+    # ---- trace-kernel time of one frame (HIP events around every trace launch), separate short pass ----
+    TRACE_FRAMES = 5
+    tr.timing_begin()
+    for _ in range(TRACE_FRAMES):
+        tr.render_device(out.data_ptr(), max_depth=a.depth, mode=mode, jitter=jitter, samples=samples, time_kernels=True)
+    tr.sync()
+    trace_ms_total, trace_launches = tr.timing_end()
 
     tot = torch.tensor([elapsed, float(rays), float(alg_bytes)], dtype=torch.float64, device=dev)
     if world > 1:
@@ -124,8 +137,15 @@ def main():
     if rank == 0:
         ms_per_step = elapsed / a.steps * 1e3
         value = rays_all * a.steps / elapsed / 1e6
-        kernel_ms = kernel_ms_total / max(launches, 1)
+        frame_ms = frame_ms_total / max(frames, 1)
+        kernel_ms = trace_ms_total / TRACE_FRAMES
         achieved = alg_bytes / (kernel_ms * 1e-3) / 1e9
+        traffic = None
+        tpath = os.path.join(REPO, "profiles", "r01_traffic.json")        # PMC passes are separate runs (tools/run_pmc.sh)
+        if os.path.exists(tpath):
+            tj = json.load(open(tpath))
+            if tj.get("workload_triangles") == int(view.num.triangleNum) and tj.get("mode") == a.mode and tj.get("builder") == a.builder:
+                traffic = tj.get("hbm_bytes_per_frame")
         dbytes = tr.scene_device_bytes()
         line = {
             "metric": "Mrays/s (whole node) at 1080p 4-bounce", "value": round(value, 2), "unit": "Mrays/s", "n_gpus": world,
@@ -138,7 +158,10 @@ def main():
                        "rays_per_frame": int(rays), "host_bvh_build_s": round(build_s, 2), "scene_upload_s": round(upload_s, 2),
                        "device_scene_bytes": dbytes},
             "roofline": {"bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-                         "frac": round(achieved / HBM_PEAK_GBPS, 5), "traffic": None, "kernel_ms": round(kernel_ms, 4),
+                         "frac": round(achieved / HBM_PEAK_GBPS, 5), "traffic": traffic, "kernel_ms": round(kernel_ms, 4),
+                         "kernel": "trace kernels of one frame (wfTraceLeanKernel + wfTraceSwarmKernel)" if a.mode == "fast" else "trace kernels of one frame (wfTraceKernel)",
+                         "launches_per_frame": trace_launches // TRACE_FRAMES, "frame_ms": round(frame_ms, 4),
+                         "frame_frac": round(alg_bytes / (frame_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS, 5),
                          "algorithmic_bytes_per_launch": int(alg_bytes),
                          "counts": {"node_visits": int(cn.nodeVisits), "tri_tests": int(cn.triTests), "sphere_tests": int(cn.sphereTests),
                                     "other_tests": int(cn.otherTests), "rays": int(rays)}},

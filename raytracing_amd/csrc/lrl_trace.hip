@@ -654,6 +654,7 @@ static int renderWavefront(LrlContext* c, const LrlRenderParams* p, const KScene
         if (FILE* fp = std::fopen(tlPath, "wb")) { std::fwrite(h.data(), 8, h.size(), fp); std::fclose(fp); }
         return LRL_OK;
     };
+    const bool poll = c->hasTransmission;    // refraction stacks make the number of segments data dependent
     if (e0) HIP_TRY(c, hipEventRecord(e0, stream));
     uint32_t iterations = 0;
     for (uint32_t s = f.sampleBegin; s < f.sampleEnd; ++s) {
@@ -667,6 +668,7 @@ static int renderWavefront(LrlContext* c, const LrlRenderParams* p, const KScene
             if ((rc = timedTrace(iter))) return rc;
             if (tl) { wf.timeline = nullptr; if ((rc = dumpTimeline())) return rc; }
             HIP_TRY(c, fast ? lrl_fast::wfLaunchShade(k, f, wf, iter, pool, stream) : lrl_parity::wfLaunchShade(k, f, wf, iter, pool, stream));
+            if (!poll) continue;   // exact bound: nothing to ask the device, the whole frame is enqueued without a host wait
             HIP_TRY(c, hipMemcpyAsync(c->aliveHost + iter, wf.alive + iter, 4, hipMemcpyDeviceToHost, stream));
             HIP_TRY(c, hipEventRecord(c->evIter[iter & 1], stream));
             if (iter >= 1) {      // look at the iteration before while this one runs: the pipeline ends one (empty) iteration late
@@ -674,7 +676,7 @@ static int renderWavefront(LrlContext* c, const LrlRenderParams* p, const KScene
                 if (c->aliveHost[iter - 1] == 0) { ++iter; break; }
             }
         }
-        if (iter == bound) {      // the last iteration has not been looked at yet
+        if (poll && iter == bound) {      // the last iteration has not been looked at yet
             HIP_TRY(c, hipEventSynchronize(c->evIter[(bound - 1) & 1]));
             if (c->aliveHost[bound - 1] != 0) return fail(c, LRL_ERR_LIMIT, "wavefront pipeline did not finish within its iteration bound");
         }
