@@ -11,6 +11,7 @@
 // The materials are written through small constructors instead of the reference's 10-field brace
 // lists; values are the reference's.
 #pragma once
+#include <stdexcept>
 #include <string>
 
 #include "RayTracing.hpp"
@@ -159,6 +160,95 @@ inline Camera mesh(Model& m, STL const& in, unsigned subdivisions) {
     Math::vec3<double> u = r.cross(f);
     for (int i = 0; i < 3; ++i) { cam.trans.data[i][0] = r[i]; cam.trans.data[i][1] = u[i]; cam.trans.data[i][2] = -f[i]; }
     cam.r0 = eye;
+    return cam;
+}
+
+
+// Pool demo: 48 x 48 water grid as 2 * 47 * 47 triangles (initModel, Pool/Pool.cpp:240-299) with the water's
+// initial heights (WaterData, :97-112) scattered into the vertices the way WaterPositionSync does
+// (Pool/shaders/WaterPositionSyncCompute0.cpp:49-74; the reference runs it once at init, Pool/Pool.cpp:649-650),
+// then the 28 triangles of pool.stl with the per-triangle materials and uv of Pool/Pool.cpp:515-606,
+// one light, four texture layers (pool, brick, ceiling, floor) and the room cube map.
+// resdir = directory holding pool.stl, pool.bmp, brick.bmp, ceiling.bmp, floor.bmp and room/.
+inline Camera pool(Model& m, std::string const& resdir, bool loadTextures = true) {
+    using Tri = Model::Triangles::TriangleOriginData::TriangleOrigin;
+    const unsigned gx = 8 * 6, gy = 8 * 6;                      // groupSize * groupNum, Pool/Pool.cpp:484
+    const float z0 = 0.4f, dx = float((1.0 - 0.01) / (8 * 6 - 1)), dzMax = 0.15f;
+    const float x0 = float(-0.5 + 0.005), y0 = float(-0.5 + 0.005);
+    m.pointLights.data.pointLights += {{{0.15, 0.15, 0.15}, {0, 0, 2.6}}};
+    Color water = material(1, 1, 0, 0, -1, 1.33f);
+    auto& tris = m.triangles.trianglesOrigin.trianglesOrigin;
+    for (unsigned c0 = 0; c0 + 1 < gy; ++c0) {
+        for (unsigned c1 = 0; c1 + 1 < gx; ++c1) {
+            Tri t{};
+            t.vertices[0] = {x0 + dx * c1, y0 + dx * c0, z0 - dzMax};
+            t.vertices[1] = {x0 + dx * (c1 + 1), y0 + dx * c0, z0 - dzMax};
+            t.vertices[2] = {x0 + dx * c1, y0 + dx * (c0 + 1), z0 + dzMax};
+            t.uv1 = {0, 0}; t.uv2 = {0, 0}; t.uv3 = {0, 0};
+            t.color = water;
+            tris.pushBack(t);
+        }
+        for (unsigned c1 = 0; c1 + 1 < gx; ++c1) {
+            Tri t{};
+            t.vertices[0] = {x0 + dx * (c1 + 1), y0 + dx * (c0 + 1), z0 - dzMax};
+            t.vertices[1] = {x0 + dx * c1, y0 + dx * (c0 + 1), z0 - dzMax};
+            t.vertices[2] = {x0 + dx * (c1 + 1), y0 + dx * c0, z0 + dzMax};
+            t.uv1 = {0, 0}; t.uv2 = {0, 0}; t.uv3 = {0, 0};
+            t.color = water;
+            tris.pushBack(t);
+        }
+    }
+    // water heights at rest (paused, Pool/Pool.cpp:463) and their scatter into the triangles
+    {
+        const float cX = float((gx - 1) / 2), cY = float((gy - 1) / 2);       // integer division, as in the reference
+        const double pi = 3.14159265358979323846;
+        for (unsigned y = 0; y < gy; ++y)
+            for (unsigned x = 0; x < gx; ++x) {
+                const float z = z0 + dzMax * 0.5f * sinf(float(2 * pi * x / cX)) * sinf(float(2 * pi * y / cY));
+                const unsigned ti = x + y * 2 * (gx - 1);
+                if (x != 0) {
+                    if (y != 0) tris[ti - gx].vertices[0][2] = z;
+                    if (y != gy - 1) { tris[ti - 1].vertices[1][2] = z; tris[ti + gx - 2].vertices[2][2] = z; }
+                }
+                if (x != gx - 1) {
+                    if (y != 0) { tris[ti - 2 * (gx - 1)].vertices[2][2] = z; tris[ti - gx + 1].vertices[1][2] = z; }
+                    if (y != gy - 1) tris[ti].vertices[0][2] = z;
+                }
+            }
+    }
+    const unsigned k = tris.length;
+    {
+        STL s = STL::readSTL(resdir + "/pool.stl");
+        m.addSTL(s, material(0, 0, 1, 0, 0, 1), s.triangles.length);
+    }
+    if (tris.length < k + 28) throw std::runtime_error("pool.stl: 28 triangles expected");
+    auto uv = [&](unsigned i, float a, float b, float c, float d, float e, float f) { tris[i].uv1 = {a, b}; tris[i].uv2 = {c, d}; tris[i].uv3 = {e, f}; };
+    for (unsigned c0 = 0; c0 < 4; ++c0) {                        // pool walls: tiled pool texture as glow, behind water
+        uv(k + 2 * c0, 5, 0, 5, 1.5f, 0, 0);
+        uv(k + 2 * c0 + 1, 0, 1.5f, 0, 0, 5, 1.5f);
+        for (unsigned i : {k + 2 * c0, k + 2 * c0 + 1}) { tris[i].color.d = 0; tris[i].color.g = 1; tris[i].color.texG = 0; tris[i].color.n = 1.33f; }
+    }
+    for (unsigned c0 = 8; c0 < 16; ++c0) { tris[k + c0].color.d = 1; tris[k + c0].color.g = 0; tris[k + c0].color.texD = 3; tris[k + c0].color.n = 1; }
+    uv(k + 16, 5, 0, 0, 0, 5, 5);                                // pool bottom
+    uv(k + 17, 0, 5, 5, 5, 0, 0);
+    for (unsigned i : {k + 16, k + 17}) { tris[i].color.g = 1; tris[i].color.texG = 0; tris[i].color.decayFactor = -1; tris[i].color.n = 1.33f; }
+    for (unsigned c0 = 9; c0 < 13; ++c0) {                       // room walls: brick
+        uv(k + 2 * c0, 1, 0, 1, 1, 0, 0);
+        uv(k + 2 * c0 + 1, 0, 1, 0, 0, 1, 1);
+        for (unsigned i : {k + 2 * c0, k + 2 * c0 + 1}) { tris[i].color.d = 1; tris[i].color.g = 0; tris[i].color.texD = 1; tris[i].color.n = 1; }
+    }
+    uv(k + 26, 1, 1, 0, 0, 1, 0);                                // ceiling
+    uv(k + 27, 1, 1, 0, 1, 0, 0);
+    for (unsigned i : {k + 26, k + 27}) { tris[i].color.d = 1; tris[i].color.g = 0; tris[i].color.texD = 2; tris[i].color.n = 1; }
+    if (loadTextures) {
+        BMPData poolBMP(resdir + "/pool.bmp"), wallBMP(resdir + "/brick.bmp"), ceilingBMP(resdir + "/ceiling.bmp"), floorBMP(resdir + "/floor.bmp");
+        m.setTextureArray({&poolBMP.bmp, &wallBMP.bmp, &ceilingBMP.bmp, &floorBMP.bmp});
+        m.setCube(BMPCubeData(resdir + "/room/"));
+    }
+    m.planes.numChanged = m.triangles.numChanged = m.spheres.numChanged = m.circles.numChanged = true;
+    m.cylinders.numChanged = m.cones.numChanged = m.pointLights.numChanged = true;
+    Camera cam;
+    cam.r0 = {0, 0, 1};                                          // Pool/Pool.cpp:465
     return cam;
 }
 

@@ -37,7 +37,9 @@ int lrlh_scene_bvh_default(Handle* h, const char* resdir, int loadCube) {
 int lrlh_scene_mesh(Handle* h, const char* stlPath, unsigned subdivisions) {
     return guarded([&] { h->cam = scenes::mesh(h->model, STL::readSTL(stlPath), subdivisions); });
 }
-int lrlh_scene_pool(Handle* h, const char* resdir, int loadTextures);   // Pool.cpp (separate TU)
+int lrlh_scene_pool(Handle* h, const char* resdir, int loadTextures) {
+    return guarded([&] { h->cam = scenes::pool(h->model, resdir, loadTextures != 0); });
+}
 
 // generic adders (records in the layouts of include/lrl_types.h)
 int lrlh_add_triangles(Handle* h, const LrlTriangle* t, unsigned n) {

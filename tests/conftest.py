@@ -57,6 +57,12 @@ def bunny0_model():
 
 
 @pytest.fixture(scope="session")
+def pool_model():
+    from raytracing_amd import scenes
+    return scenes.pool()
+
+
+@pytest.fixture(scope="session")
 def tracer():
     from raytracing_amd import tracer as T
     t = T.Tracer(0)

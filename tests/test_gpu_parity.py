@@ -22,7 +22,7 @@ RMSE_PARITY = 1e-4
 RMSE_FAST = 5e-3
 
 
-def run_golden(tracer, model, name, mode, jitter=None, decay=(0, 0, 0, 1)):
+def run_golden(tracer, model, name, mode, jitter=None, decay=(0, 0, 0, 1), id_bar=ID_BAR):
     g = load_golden(name)
     tracer.scene_upload(model.scene_view())
     tracer.set_camera(g["trans"], g["width"], g["height"])
@@ -30,7 +30,7 @@ def run_golden(tracer, model, name, mode, jitter=None, decay=(0, 0, 0, 1)):
     img, hits = tracer.render(max_depth=g["depth"], variant=g["variant"], mode=mode, jitter=jitter)
     same = (hits == g["ids"]).all(axis=-1).mean()
     st = image_stats(img, g["rgb"])
-    assert same >= ID_BAR, (name, mode, same)
+    assert same >= id_bar, (name, mode, same)
     assert st["rmse"] <= (RMSE_PARITY if mode == abi.MODE_PARITY else RMSE_FAST), (name, mode, st)
     assert np.all(img[..., 3] == 1.0)
     return st
@@ -284,3 +284,53 @@ def test_wavefront_and_megakernel_schedules_agree_bit_for_bit(tracer, default_mo
     assert np.array_equal(out[False][0].view(np.uint32), out[True][0].view(np.uint32))
     assert np.array_equal(out[False][1], out[True][1])
     assert out[False][2] == out[True][2]
+
+
+# ---- Pool variant on the Pool demo scene (water surface refraction / reflection, four texture layers) ----
+@pytest.mark.parametrize("mode", [abi.MODE_PARITY, abi.MODE_FAST])
+@pytest.mark.parametrize("name", ["pool_viewA_160", "pool_viewB_192", "pool_underwater_128"])
+def test_pool_scene_vs_llvmpipe_golden(tracer, pool_model, name, mode):
+    """PARITY: 100 % of the ids.  View A looks along the diagonal of the water grid, so the pixels on the image diagonal
+    x + y = 159 shoot rays exactly through edges shared by two water triangles (ids 47 apart): a true tie that FAST
+    arithmetic (fma, rcp) may give to the neighbour.  7 of 25600 pixels do (tools/diag_pool.py lists them), all on that
+    diagonal; the FAST bar for this one view is therefore 99.95 %."""
+    tie_view = name == "pool_viewA_160" and mode == abi.MODE_FAST
+    run_golden(tracer, pool_model, name, mode, id_bar=0.9995 if tie_view else ID_BAR)
+
+
+def test_pool_decay_origin_and_water_update(tracer, pool_model):
+    """DecayOriginPre / DecayOrigin, Pool probe (+z), eye under water; then lrl_scene_update_triangles on the water
+    triangles (what Pool does every frame, Pool/Pool.cpp:654-655): writing the same triangles back changes nothing,
+    a lowered surface changes the image, in PARITY and in FAST mode (whose wide / lean kernels keep copies of the
+    triangle records)."""
+    g = load_golden("pool_underwater_128")
+    view = pool_model.scene_view()
+    tracer.scene_upload(view)
+    tracer.set_camera(g["trans"], g["width"], g["height"])
+    d = tracer.compute_decay_origin(abi.VARIANT_POOL)
+    np.testing.assert_allclose(d["decayOrigin"], [-1, -1, -1, 1.33], rtol=1e-6)
+    od = O.decay_origin(view, g["trans"], variant=abi.VARIANT_POOL)
+    np.testing.assert_array_equal(d["decayOrigin"], od["decayOrigin"])
+    g2 = load_golden("pool_viewB_192")
+    tracer.set_camera(g2["trans"], g2["width"], g2["height"])
+    tracer.set_decay_origin((0, 0, 0, 1))
+    base, _ = tracer.render(max_depth=8, variant=abi.VARIANT_POOL)
+    arr = pool_model.arrays()
+    water = arr["triangles"][: 2 * 47 * 47].copy()
+    tracer.update_triangles(0, water)
+    same, _ = tracer.render(max_depth=8, variant=abi.VARIANT_POOL)
+    assert np.array_equal(base, same)
+    moved = water.copy()
+    for f in ("p1", "p2", "p3"):
+        moved[f][:, 2] -= 0.05
+    tracer.update_triangles(0, moved)
+    low, _ = tracer.render(max_depth=8, variant=abi.VARIANT_POOL)
+    assert not np.array_equal(base, low)
+    tracer.update_triangles(0, water)                       # and back: TrianglePre is a pure function of the triangles
+    again, _ = tracer.render(max_depth=8, variant=abi.VARIANT_POOL)
+    assert np.array_equal(base, again)
+    fast0, _ = tracer.render(max_depth=8, variant=abi.VARIANT_POOL, mode=abi.MODE_FAST)   # the FAST kernels see the update too
+    tracer.update_triangles(0, moved)
+    fast1, _ = tracer.render(max_depth=8, variant=abi.VARIANT_POOL, mode=abi.MODE_FAST)
+    assert image_stats(fast0, base)["rmse"] <= RMSE_FAST and image_stats(fast1, low)["rmse"] <= RMSE_FAST
+    tracer.update_triangles(0, water)

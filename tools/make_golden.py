@@ -78,6 +78,35 @@ def make_assets(ref):
     print(f"bunny: {n} triangles, {verts.shape[0]} vertices, {int(flip.sum())} flipped")
 
 
+def make_pool_assets(ref):
+    """Pool textures box-filtered 1024^2 -> 128^2 (floor.bmp 1016x1024 -> 127x128: it stays narrower than its layer, as in
+    the reference, Pool/Pool.cpp:491-492), the room cube 512^2 -> 128^2, pool.stl as it is."""
+    res = os.path.join(ref, "Pool", "resources")
+    dst = scenes.POOL_RESOURCES
+    os.makedirs(os.path.join(dst, "room"), exist_ok=True)
+    shutil.copyfile(os.path.join(res, "pool.stl"), os.path.join(dst, "pool.stl"))
+    for name in ("pool", "brick", "ceiling", "floor"):
+        a = read_bmp(os.path.join(res, name + ".bmp"))
+        write_bmp(os.path.join(dst, name + ".bmp"), box_filter(a, 8))
+    for face in ("front", "back", "down", "up", "right", "left"):
+        a = read_bmp(os.path.join(res, "room", face + ".bmp"))
+        write_bmp(os.path.join(dst, "room", face + ".bmp"), box_filter(a, a.shape[0] // 128))
+
+
+def make_pool_goldens(ref):
+    """Pool variant of the fragment shader (no checker, RayTraceDepth 8) on the Pool demo scene."""
+    shaders = os.path.join(ref, "Pool", "shaders")
+    m = scenes.pool()
+    tA = m.camera(160)                     # the reference's start pose: (0,0,1) looking down at the water
+    save("pool_viewA_160", O.run_reference(m, tA, 160, 160, shaders), tA, dict(width=160, height=160, depth=8, variant=1))
+    m.camera_look_at(60.0, (0.42, -0.44, 0.9), (0.0, 0.1, 0.35))      # oblique: walls, ceiling, water, pool bottom
+    tB = m.camera(192)
+    save("pool_viewB_192", O.run_reference(m, tB, 192, 192, shaders), tB, dict(width=192, height=192, depth=8, variant=1))
+    m.camera_look_at(60.0, (0.2, -0.2, 0.2), (0.0, 0.3, 0.45))        # camera under water: DecayOriginPre (+z probe) decides the medium
+    tC = m.camera(128)
+    save("pool_underwater_128", O.run_reference(m, tC, 128, 128, shaders, decay_compute=True), tC, dict(width=128, height=128, depth=8, variant=1))
+
+
 def save(name, ref, trans, meta):
     ids = ref["ids"]
     np.savez_compressed(os.path.join(GOLDEN, name + ".npz"), rgb=ref["img"][..., :3].copy(), hit_type=ids[..., 0].astype(np.uint8),
@@ -89,9 +118,14 @@ def save(name, ref, trans, meta):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--reference", default="/root/reference")
+    ap.add_argument("--only", default="", help="'pool': only the Pool assets and goldens")
     a = ap.parse_args()
     ref = a.reference
     os.makedirs(GOLDEN, exist_ok=True)
+    if a.only == "pool":
+        make_pool_assets(ref)
+        make_pool_goldens(ref)
+        return
     make_assets(ref)
     bvh_shaders = os.path.join(ref, "BVH", "shaders")
 
@@ -130,6 +164,9 @@ def main():
     mm = scenes.mesh_scene(subdivisions=0, builder="median")
     tM = mm.camera(135)
     save("mesh_bunny0_240x135_depth4", O.run_reference(mm, tM, 240, 135, bvh_shaders, max_depth=4), tM, dict(width=240, height=135, depth=4, variant=0))
+
+    make_pool_assets(ref)
+    make_pool_goldens(ref)
 
 
 if __name__ == "__main__":
