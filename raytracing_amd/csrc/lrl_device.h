@@ -10,6 +10,12 @@
 //             record: a leaf visit costs no node fetch.  father / blank of the reference's 64-B node are
 //             dropped: traversal keeps a per-lane stack of pending far children in LDS instead of the
 //             reference's parent-pointer trail.
+//   node4     4 x uint4 per node of the four-wide collapse of the same tree (64 B), child boxes as bytes relative to the
+//             node's origin and power-of-two units (layout at buildNode4, lrl_trace.hip); indexed by the record index of
+//             the binary node it replaces, so refs are shared with `recs`.  FAST lean kernel only.  Why: the vector L1
+//             charges per lane and per 16-byte piece (tools/probes/l1_gather.hip: 171 CU-cycles for a wave whose lanes
+//             each read their own 64 B from L1) and that, not arithmetic, bounds a one-lane-per-ray traversal: four
+//             children per 64 B halve both the fetches and the chain of dependent trips of a ray.
 //   triHot    4 x float4 per triangle (64 B, one half cache line): plane | p1,k1.x | k1.yz,k2.xy | k2.z
 //   triCold   32 B per triangle: uv1 uv2 uv3, material index   (read once per accepted hit)
 //   materials 80-B Color records, de-duplicated on upload (a mesh usually has a handful)
@@ -47,6 +53,7 @@ static_assert(sizeof(LrlTriCold) == 32, "TriCold");
 
 struct KScene {
     const float4* recs;
+    const uint4* node4;      // four-wide compressed nodes, 4 x uint4 each, indexed like recs (FAST lean kernel)
     const float4* wide;      // 4-wide repack (lrl_wide.inc): 16 float4 per node
     const float4* triHot;
     const LrlTriCold* triCold;
@@ -104,7 +111,10 @@ enum { LRL_CTR_PRIMARY = 0, LRL_CTR_REFLECT, LRL_CTR_REFRACT, LRL_CTR_SHADOW, LR
 #define LRL_WF_TRACE_WAVES 8      /* __launch_bounds__ waves per SIMD of the trace kernel */
 #endif
 #ifndef LRL_WF_LEAN_WAVES
-#define LRL_WF_LEAN_WAVES 6       /* __launch_bounds__ waves per SIMD of the lean trace kernel */
+#define LRL_WF_LEAN_WAVES 8       /* __launch_bounds__ waves per SIMD of the lean trace kernel (64 VGPRs) */
+#endif
+#ifndef LRL_LEAN_STACK
+#define LRL_LEAN_STACK 8          /* its LDS rows of parked children per lane (8 rows + 1: 32 waves per CU fit in 160 KB) */
 #endif
 #ifndef LRL_W4_WAVES
 #define LRL_W4_WAVES 6            /* __launch_bounds__ waves per SIMD of the 4-wide trace kernel */
@@ -130,6 +140,8 @@ struct WFrame {
     uint32_t tilesX;         // 8x8 tiles per row of tiles
     uint32_t sample;         // sample index rendered by this pass
     uint32_t overflowEntries;   // per-lane entries of `overflow` (0: the LDS stack always suffices)
+    uint32_t tilesY;         // rows of tiles
+    uint32_t xcdBlock;       // lean trace kernel: edge (in tiles) of the square pixel blocks dealt out to the 8 XCDs; 0 = workgroup i takes word i
     float4* answer;          // xyz accumulated colour, w = v of the pending light terms
     float4* ratio;           // ratioNow
     float4* decay;           // decayNow

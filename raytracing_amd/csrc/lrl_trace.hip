@@ -4,6 +4,7 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <cmath>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -45,7 +46,7 @@ struct LrlContext {
     LrlGeometryNum num{};
     uint32_t nodeNum = 0, recNum = 0, bvhDepth = 0, wideNodes = 0, wideDepth = 0;
     DevBuf wide;
-    DevBuf nodes, triHot, triCold, materials, spheres, circles, cylinders, cones, lights, tex, cube, triStage, matStage;
+    DevBuf nodes, nodes32, triHot, triCold, materials, spheres, circles, cylinders, cones, lights, tex, cube, triStage, matStage;
     uint32_t texW = 0, texH = 0, texL = 0, cubeSize = 0;
     std::vector<LrlColor> materialTable;
     std::unordered_map<ColorKey, uint32_t, ColorHash> materialIndex;
@@ -54,6 +55,7 @@ struct LrlContext {
     LrlTrans trans{};
     uint32_t width = 0, height = 0;
     float decayOrigin[4] = {0, 0, 0, 1};
+    uint32_t node4Depth = 0;   // depth of the four-wide tree (nodes32)
     DevBuf transDev, outDev, hitDev, counterDev, decayDev, timelineDev;
     DevBuf wfArena;                     // wavefront pipeline: path state, ray records, masks, refraction stacks, overflow stacks
     uint32_t* aliveHost = nullptr;      // pinned: per-iteration "any path alive" words copied back while the next iteration runs
@@ -150,6 +152,7 @@ int validateBVH(LrlContext* c, const LrlSceneView* s, uint32_t& depthOut) {
 
 void fillKScene(const LrlContext* c, KScene& k) {
     k.recs = static_cast<const float4*>(c->nodes.p);
+    k.node4 = static_cast<const uint4*>(c->nodes32.p);
     k.wide = static_cast<const float4*>(c->wide.p);
     k.triHot = static_cast<const float4*>(c->triHot.p);
     k.triCold = static_cast<const LrlTriCold*>(c->triCold.p);
@@ -173,6 +176,113 @@ std::vector<uchar4> bgrToRgbx(const uint8_t* bgr, size_t texels) {
     return o;
 }
 
+
+// Four-wide, compressed repack of the caller's binary tree for the FAST lean kernel (lrl_lean.inc).  A node's items are
+// its parked primitive and its children; an inner child is replaced by ITS items while the node stays within four (largest
+// box first).  The node of binary inner node b is stored at b's record index (recOf[b], the index `recs` uses), so refs mean
+// the same in both trees and a ray can change from one to the other at any ref; record indices of binary nodes that were
+// merged into their parent stay unused.  64 B per node:
+//   {origin.x, origin.y, origin.z, ex | ey << 8 | ez << 16}     origin = min corner of the items' boxes; e* = float exponent
+//                                                                field of the per-axis unit (a power of two)
+//   {lo.x of items 0..3 (one byte each), lo.y, lo.z, hi.x}       box = origin + byte * unit, rounded outwards
+//   {hi.y, hi.z, ref0, ref1}  {ref2, ref3, 0, 0}                 ref: LRL_REF_NONE, record index, or LRL_REF_LEAF | primitive
+std::vector<uint4> buildNode4(const LrlSceneView* s, const std::vector<uint32_t>& recOf, uint32_t recCount, uint32_t& depthOut) {
+    const LrlBVHNode* bvh = s->bvh;
+    struct Item { bool inner; uint32_t ref; uint32_t boxOf; };      // inner: binary node index; else primitive bits; boxOf: binary node whose box bounds it
+    auto primOf = [&](const LrlBVHNode& n) { return (uint32_t(n.geometry) << LRL_PRIM_TYPE_SHIFT) | (n.geometryNum & LRL_PRIM_INDEX_MASK); };
+    auto asItem = [&](uint32_t cnode, Item* out, int& k) {
+        if (bvh[cnode].bound.leftChild) out[k++] = {true, cnode, cnode};
+        else if (bvh[cnode].geometry) out[k++] = {false, primOf(bvh[cnode]), cnode};
+    };
+    auto contents = [&](uint32_t b, Item* out) -> int {
+        const LrlBVHNode& n = bvh[b];
+        int k = 0;
+        if (n.geometry) out[k++] = {false, primOf(n), b};
+        if (n.bound.leftChild) {
+            asItem(b + 1, out, k);
+            if (n.bound.rightChild) asItem(uint32_t(n.bound.rightChild), out, k);
+        }
+        return k;
+    };
+    auto area = [&](uint32_t b) {
+        const LrlBound& q = bvh[b].bound;
+        float dx = q.max[0] - q.min[0], dy = q.max[1] - q.min[1], dz = q.max[2] - q.min[2];
+        return dx * dy + dy * dz + dz * dx;
+    };
+    auto fb = [](float f) { uint32_t v; std::memcpy(&v, &f, 4); return v; };
+    std::vector<uint4> out(size_t(recCount) * 4, make_uint4(0, 0, LRL_REF_NONE, LRL_REF_NONE));
+    struct Work { uint32_t bin; bool virt; uint32_t depth; };
+    std::vector<Work> work;
+    work.push_back({0u, true, 0u});
+    uint32_t depth = 0;
+    while (!work.empty()) {
+        const Work w = work.back();
+        work.pop_back();
+        depth = std::max(depth, w.depth);
+        Item items[8];
+        int n = 0;
+        if (w.virt) asItem(0u, items, n);      // record 0: the virtual parent of the root
+        else n = contents(w.bin, items);
+        for (;;) {
+            int best = -1;
+            float bestArea = -1.0f;
+            Item sub[3];
+            for (int i = 0; i < n; ++i) {
+                if (!items[i].inner) continue;
+                const int add = contents(items[i].ref, sub);
+                if (n - 1 + add > 4) continue;
+                const float a = area(items[i].ref);
+                if (a > bestArea) { bestArea = a; best = i; }
+            }
+            if (best < 0) break;
+            const int add = contents(items[best].ref, sub);
+            for (int i = best; i + 1 < n; ++i) items[i] = items[i + 1];
+            --n;
+            for (int i = 0; i < add; ++i) items[n++] = sub[i];
+        }
+        uint4* q = &out[size_t(w.virt ? 0u : recOf[w.bin]) * 4];
+        double lo[3] = {1e300, 1e300, 1e300}, hi[3] = {-1e300, -1e300, -1e300};
+        for (int i = 0; i < n; ++i)
+            for (int a = 0; a < 3; ++a) {
+                lo[a] = std::min(lo[a], double(bvh[items[i].boxOf].bound.min[a]));
+                hi[a] = std::max(hi[a], double(bvh[items[i].boxOf].bound.max[a]));
+            }
+        float origin[3] = {0, 0, 0};
+        uint32_t expo[3] = {127, 127, 127};
+        double unit[3] = {1, 1, 1};
+        for (int a = 0; a < 3 && n; ++a) {
+            origin[a] = float(lo[a]);
+            if (double(origin[a]) > lo[a]) origin[a] = std::nextafter(origin[a], -INFINITY);
+            const double ext = hi[a] - double(origin[a]);
+            int e = ext > 0 ? int(std::ceil(std::log2(ext / 255.0))) : -126;
+            e = std::min(127, std::max(-126, e));
+            while (e < 127 && std::ceil(ext / std::ldexp(1.0, e)) > 255.0) ++e;
+            expo[a] = uint32_t(e + 127);
+            unit[a] = std::ldexp(1.0, e);
+        }
+        uint32_t bytes[6] = {0, 0, 0, 0, 0, 0};      // lo.x lo.y lo.z hi.x hi.y hi.z, item i in byte i
+        uint32_t refs[4] = {LRL_REF_NONE, LRL_REF_NONE, LRL_REF_NONE, LRL_REF_NONE};
+        for (int i = 0; i < n; ++i) {
+            const LrlBound& bb = bvh[items[i].boxOf].bound;
+            for (int a = 0; a < 3; ++a) {
+                const double ql = std::floor((double(bb.min[a]) - double(origin[a])) / unit[a]);
+                const double qh = std::ceil((double(bb.max[a]) - double(origin[a])) / unit[a]);
+                bytes[a] |= uint32_t(std::min(255.0, std::max(0.0, ql))) << (8 * i);
+                bytes[3 + a] |= uint32_t(std::min(255.0, std::max(0.0, qh))) << (8 * i);
+            }
+            if (items[i].inner) {
+                refs[i] = recOf[items[i].ref];
+                work.push_back({items[i].ref, false, w.depth + 1});
+            } else refs[i] = LRL_REF_LEAF | items[i].ref;
+        }
+        q[0] = make_uint4(fb(origin[0]), fb(origin[1]), fb(origin[2]), expo[0] | expo[1] << 8 | expo[2] << 16);
+        q[1] = make_uint4(bytes[0], bytes[1], bytes[2], bytes[3]);
+        q[2] = make_uint4(bytes[4], bytes[5], refs[0], refs[1]);
+        q[3] = make_uint4(refs[2], refs[3], 0u, 0u);
+    }
+    depthOut = depth;
+    return out;
+}
 
 // 4-wide repack of the caller's binary tree for lrl_wide.inc: a node's items are its parked primitive and its children;
 // an inner child is replaced by ITS items while the node stays within four slots (largest box first).  Same boxes, same
@@ -304,7 +414,7 @@ int lrl_destroy(LrlContext* c) {
     if (!c) return LRL_ERR_INVALID_ARG;
     (void)hipSetDevice(c->device);
     (void)hipStreamSynchronize(c->stream);
-    for (DevBuf* b : {&c->wide, &c->nodes, &c->triHot, &c->triCold, &c->materials, &c->spheres, &c->circles, &c->cylinders, &c->cones, &c->lights,
+    for (DevBuf* b : {&c->wide, &c->nodes, &c->nodes32, &c->triHot, &c->triCold, &c->materials, &c->spheres, &c->circles, &c->cylinders, &c->cones, &c->lights,
                       &c->tex, &c->cube, &c->triStage, &c->matStage, &c->transDev, &c->outDev, &c->hitDev, &c->counterDev, &c->decayDev, &c->timelineDev, &c->wfArena})
         release(*b);
     for (auto& e : c->timingEvents) { (void)hipEventDestroy(e.first); (void)hipEventDestroy(e.second); }
@@ -375,6 +485,13 @@ int lrl_scene_upload(LrlContext* c, const LrlSceneView* s) {
         rc = upload(c, c->nodes, packed.data(), packed.size() * sizeof(float4));
         if (rc) return rc;
         HIP_TRY(c, hipStreamSynchronize(c->stream));
+        // the same tree collapsed to four children per node with 8-bit child boxes, for the FAST lean kernel (lrl_lean.inc)
+        uint32_t depth4 = 0;
+        std::vector<uint4> node4 = buildNode4(s, recOf, recCount, depth4);
+        c->node4Depth = depth4;
+        rc = upload(c, c->nodes32, node4.data(), node4.size() * sizeof(uint4));
+        if (rc) return rc;
+        HIP_TRY(c, hipStreamSynchronize(c->stream));
     }
     {
         c->wideNodes = 0;
@@ -385,7 +502,7 @@ int lrl_scene_upload(LrlContext* c, const LrlSceneView* s) {
         HIP_TRY(c, hipStreamSynchronize(c->stream));
         c->wideDepth = wd;
         c->wideNodes = wn;
-        if (std::getenv("LRL_DEBUG")) std::fprintf(stderr, "lrl: binary nodes %u (depth %u) -> 4-wide nodes %u (depth %u)\n", s->bvhNodeNum, depth, wn, wd);
+        if (std::getenv("LRL_DEBUG")) std::fprintf(stderr, "lrl: binary nodes %u (depth %u) -> 4-wide nodes %u (depth %u), compressed four-wide tree depth %u\n", s->bvhNodeNum, depth, wn, wd, c->node4Depth);
     }
     c->materialTable.clear();
     c->materialIndex.clear();
@@ -567,7 +684,10 @@ static int renderWavefront(LrlContext* c, const LrlRenderParams* p, const KScene
     if (special && which && !std::strcmp(which, "wide1")) leanIters = 0;
     const uint32_t wideNeed = 3 * c->wideDepth + 4;
     const uint32_t ovfW = wideNeed > uint32_t(LRL_W4_STACK) ? wideNeed - uint32_t(LRL_W4_STACK) : 0u;
-    const uint32_t ovfN = c->bvhDepth + 1 > uint32_t(LRL_WF_STACK) ? c->bvhDepth + 1 - uint32_t(LRL_WF_STACK) : 0u;
+    // deepest stack: one parked child per level of the binary tree (wfTraceKernel), three per level of the four-wide tree (lean)
+    const uint32_t stackNeed = special ? std::max(c->bvhDepth + 1, 3 * c->node4Depth + 4) : c->bvhDepth + 1;
+    const uint32_t ldsRows = special ? uint32_t(LRL_LEAN_STACK) : uint32_t(LRL_WF_STACK);
+    const uint32_t ovfN = stackNeed > ldsRows ? stackNeed - ldsRows : 0u;
     const size_t raysAll = P * (1 + size_t(L));
     const size_t ovfBytes = std::max(size_t(chunks) * ovfN * 512, special ? (raysAll / 16) * ovfW * 128 : size_t(0));
     const uint32_t refrEntries = c->hasTransmission ? p->maxDepth : 0u;
@@ -577,7 +697,7 @@ static int renderWavefront(LrlContext* c, const LrlRenderParams* p, const KScene
     const size_t oState = take(P * 16 * 8), oFlags = take(P * 4), oRayQ = take(P * (1 + size_t(L)) * 32), oMaskC = take(size_t(words) * 8),
                  oMaskS = take(size_t(words) * 8), oRefr = take(P * 64 * refrEntries), oOvf = take(ovfBytes),
                  oAlive = take(LRL_WF_MAX_ITERATIONS * 4 * 2);
-    const uint32_t contSlots = 65536, contStride = c->bvhDepth + 2;
+    const uint32_t contSlots = 65536, contStride = stackNeed + 1;
     const size_t oContHead = take(size_t(contSlots) * 16), oContRefs = take(size_t(contSlots) * contStride * 4);
     int rc = ensure(c, c->wfArena, off);
     if (rc) return rc;
@@ -588,7 +708,9 @@ static int renderWavefront(LrlContext* c, const LrlRenderParams* p, const KScene
     }
     char* base = static_cast<char*>(c->wfArena.p);
     WFrame wf{};
-    wf.P = uint32_t(P); wf.words = words; wf.tilesX = tilesX; wf.overflowEntries = ovfN;
+    wf.P = uint32_t(P); wf.words = words; wf.tilesX = tilesX; wf.tilesY = tilesY; wf.overflowEntries = ovfN;
+    const char* xcd = std::getenv("LRL_XCD_BLOCK");
+    wf.xcdBlock = xcd ? uint32_t(std::atoi(xcd)) : 0u;
     float4* st = reinterpret_cast<float4*>(base + oState);
     wf.answer = st; wf.ratio = st + P; wf.decay = st + 2 * P; wf.rayO = st + 3 * P; wf.rayD = st + 4 * P; wf.hit = st + 5 * P;
     wf.pendA = st + 6 * P; wf.pendB = st + 7 * P;
@@ -602,7 +724,7 @@ static int renderWavefront(LrlContext* c, const LrlRenderParams* p, const KScene
     uint32_t* const contCounts = wf.alive + LRL_WF_MAX_ITERATIONS;      // one per iteration, zeroed with `alive`
     const char* ho = std::getenv("LRL_HANDOVER");
     const char* hoLate = std::getenv("LRL_HANDOVER_LATE");
-    const uint32_t handoverEarly = ho ? uint32_t(std::atoi(ho)) : 128u, handoverLate = hoLate ? uint32_t(std::atoi(hoLate)) : 64u;
+    const uint32_t handoverEarly = ho ? uint32_t(std::atoi(ho)) : 64u, handoverLate = hoLate ? uint32_t(std::atoi(hoLate)) : 32u;
     wf.handoverTrips = handoverEarly;
     wf.contSlots = contSlots; wf.contStride = contStride;
     wf.contHead = reinterpret_cast<uint4*>(base + oContHead);

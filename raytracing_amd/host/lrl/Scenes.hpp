@@ -164,10 +164,34 @@ inline Camera mesh(Model& m, STL const& in, unsigned subdivisions) {
 }
 
 
-// Pool demo: 48 x 48 water grid as 2 * 47 * 47 triangles (initModel, Pool/Pool.cpp:240-299) with the water's
-// initial heights (WaterData, :97-112) scattered into the vertices the way WaterPositionSync does
-// (Pool/shaders/WaterPositionSyncCompute0.cpp:49-74; the reference runs it once at init, Pool/Pool.cpp:649-650),
-// then the 28 triangles of pool.stl with the per-triangle materials and uv of Pool/Pool.cpp:515-606,
+// Water heights at rest (WaterData, Pool/Pool.cpp:97-112; paused, :463) scattered into the triangle vertices the way
+// WaterPositionSync does (Pool/shaders/WaterPositionSyncCompute0.cpp:49-74).  The reference runs it once at init AFTER
+// model.dataInit() (Pool/Pool.cpp:649-650): the BVH is built over the tall proxy triangles of initModel, whose boxes
+// (z0 +- dzMax) hold every height the water can take.  Call it after Model::dataInit().
+inline void poolWaterSync(Model& m) {
+    const unsigned gx = 8 * 6, gy = 8 * 6;
+    const float z0 = 0.4f, dzMax = 0.15f;
+    auto& tris = m.triangles.trianglesOrigin.trianglesOrigin;
+    if (tris.length < 2 * (gx - 1) * (gy - 1)) throw std::runtime_error("poolWaterSync: not the pool scene");
+    const float cX = float((gx - 1) / 2), cY = float((gy - 1) / 2);       // integer division, as in the reference
+    const double pi = 3.14159265358979323846;
+    for (unsigned y = 0; y < gy; ++y)
+        for (unsigned x = 0; x < gx; ++x) {
+            const float z = z0 + dzMax * 0.5f * sinf(float(2 * pi * x / cX)) * sinf(float(2 * pi * y / cY));
+            const unsigned ti = x + y * 2 * (gx - 1);
+            if (x != 0) {
+                if (y != 0) tris[ti - gx].vertices[0][2] = z;
+                if (y != gy - 1) { tris[ti - 1].vertices[1][2] = z; tris[ti + gx - 2].vertices[2][2] = z; }
+            }
+            if (x != gx - 1) {
+                if (y != 0) { tris[ti - 2 * (gx - 1)].vertices[2][2] = z; tris[ti - gx + 1].vertices[1][2] = z; }
+                if (y != gy - 1) tris[ti].vertices[0][2] = z;
+            }
+        }
+}
+
+// Pool demo: 48 x 48 water grid as 2 * 47 * 47 tall proxy triangles (initModel, Pool/Pool.cpp:240-299; the heights come
+// from poolWaterSync after the BVH is built), then the 28 triangles of pool.stl with the per-triangle materials and uv of Pool/Pool.cpp:515-606,
 // one light, four texture layers (pool, brick, ceiling, floor) and the room cube map.
 // resdir = directory holding pool.stl, pool.bmp, brick.bmp, ceiling.bmp, floor.bmp and room/.
 inline Camera pool(Model& m, std::string const& resdir, bool loadTextures = true) {
@@ -197,24 +221,6 @@ inline Camera pool(Model& m, std::string const& resdir, bool loadTextures = true
             t.color = water;
             tris.pushBack(t);
         }
-    }
-    // water heights at rest (paused, Pool/Pool.cpp:463) and their scatter into the triangles
-    {
-        const float cX = float((gx - 1) / 2), cY = float((gy - 1) / 2);       // integer division, as in the reference
-        const double pi = 3.14159265358979323846;
-        for (unsigned y = 0; y < gy; ++y)
-            for (unsigned x = 0; x < gx; ++x) {
-                const float z = z0 + dzMax * 0.5f * sinf(float(2 * pi * x / cX)) * sinf(float(2 * pi * y / cY));
-                const unsigned ti = x + y * 2 * (gx - 1);
-                if (x != 0) {
-                    if (y != 0) tris[ti - gx].vertices[0][2] = z;
-                    if (y != gy - 1) { tris[ti - 1].vertices[1][2] = z; tris[ti + gx - 2].vertices[2][2] = z; }
-                }
-                if (x != gx - 1) {
-                    if (y != 0) { tris[ti - 2 * (gx - 1)].vertices[2][2] = z; tris[ti - gx + 1].vertices[1][2] = z; }
-                    if (y != gy - 1) tris[ti].vertices[0][2] = z;
-                }
-            }
     }
     const unsigned k = tris.length;
     {

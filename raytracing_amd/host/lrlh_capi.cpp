@@ -21,6 +21,7 @@ template <class F> int guarded(F&& f) {
 struct Handle {
     Model model;
     scenes::Camera cam;
+    bool poolWaterPending = false;   // scenes::pool was built; the water heights follow the BVH build
 };
 }  // namespace
 
@@ -38,7 +39,7 @@ int lrlh_scene_mesh(Handle* h, const char* stlPath, unsigned subdivisions) {
     return guarded([&] { h->cam = scenes::mesh(h->model, STL::readSTL(stlPath), subdivisions); });
 }
 int lrlh_scene_pool(Handle* h, const char* resdir, int loadTextures) {
-    return guarded([&] { h->cam = scenes::pool(h->model, resdir, loadTextures != 0); });
+    return guarded([&] { h->cam = scenes::pool(h->model, resdir, loadTextures != 0); h->poolWaterPending = true; });
 }
 
 // generic adders (records in the layouts of include/lrl_types.h)
@@ -104,6 +105,7 @@ int lrlh_data_init(Handle* h, int builder) {
     return guarded([&] {
         h->model.builder = builder ? Model::Builder::Median : Model::Builder::Reference;
         h->model.dataInit();
+        if (h->poolWaterPending) { scenes::poolWaterSync(h->model); h->poolWaterPending = false; }   // Pool/Pool.cpp:649-650: after dataInit
     });
 }
 int lrlh_scene_view(Handle* h, LrlSceneView* out) { return guarded([&] { *out = h->model.sceneView(); }); }
