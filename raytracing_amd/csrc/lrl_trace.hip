@@ -182,10 +182,10 @@ std::vector<uchar4> bgrToRgbx(const uint8_t* bgr, size_t texels) {
 // box first).  The node of binary inner node b is stored at b's record index (recOf[b], the index `recs` uses), so refs mean
 // the same in both trees and a ray can change from one to the other at any ref; record indices of binary nodes that were
 // merged into their parent stay unused.  64 B per node:
-//   {origin.x, origin.y, origin.z, ex | ey << 8 | ez << 16}     origin = min corner of the items' boxes; e* = float exponent
-//                                                                field of the per-axis unit (a power of two)
+//   {origin.x, origin.y, origin.z, unit.x}                       origin = min corner of the items' boxes; unit = per-axis
+//                                                                length of one byte step, a power of two (as a float)
 //   {lo.x of items 0..3 (one byte each), lo.y, lo.z, hi.x}       box = origin + byte * unit, rounded outwards
-//   {hi.y, hi.z, ref0, ref1}  {ref2, ref3, 0, 0}                 ref: LRL_REF_NONE, record index, or LRL_REF_LEAF | primitive
+//   {hi.y, hi.z, ref0, ref1}  {ref2, ref3, unit.y, unit.z}       ref: LRL_REF_NONE, record index, or LRL_REF_LEAF | primitive
 std::vector<uint4> buildNode4(const LrlSceneView* s, const std::vector<uint32_t>& recOf, uint32_t recCount, uint32_t& depthOut) {
     const LrlBVHNode* bvh = s->bvh;
     struct Item { bool inner; uint32_t ref; uint32_t boxOf; };      // inner: binary node index; else primitive bits; boxOf: binary node whose box bounds it
@@ -275,10 +275,10 @@ std::vector<uint4> buildNode4(const LrlSceneView* s, const std::vector<uint32_t>
                 work.push_back({items[i].ref, false, w.depth + 1});
             } else refs[i] = LRL_REF_LEAF | items[i].ref;
         }
-        q[0] = make_uint4(fb(origin[0]), fb(origin[1]), fb(origin[2]), expo[0] | expo[1] << 8 | expo[2] << 16);
+        q[0] = make_uint4(fb(origin[0]), fb(origin[1]), fb(origin[2]), expo[0] << 23);
         q[1] = make_uint4(bytes[0], bytes[1], bytes[2], bytes[3]);
         q[2] = make_uint4(bytes[4], bytes[5], refs[0], refs[1]);
-        q[3] = make_uint4(refs[2], refs[3], 0u, 0u);
+        q[3] = make_uint4(refs[2], refs[3], expo[1] << 23, expo[2] << 23);
     }
     depthOut = depth;
     return out;
