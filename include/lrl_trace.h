@@ -149,7 +149,8 @@ int lrl_last_kernel_ms(LrlContext* ctx, float* ms);
 #define LRL_MAX_TIMED_LAUNCHES 4096u
 int lrl_timing_begin(LrlContext* ctx);
 int lrl_timing_end(LrlContext* ctx, double* total_ms, uint32_t* launches);
-/* device memory held for the scene (bytes), by class: nodes, triangle hot, triangle cold, other */
+/* device memory held for the scene (bytes), by class: nodes (binary records + four-wide nodes), triangle hot,
+ * triangle cold, other */
 int lrl_scene_device_bytes(LrlContext* ctx, uint64_t out[4]);
 
 #ifdef __cplusplus

@@ -3,7 +3,6 @@
 #define LRL_FAST 1
 #define LRL_NS lrl_fast
 #include "lrl_kernels.inc"
-#include "lrl_wide.inc"
 #include "lrl_lean.inc"
 
 hipError_t lrl_launch_render_fast(const KScene& sc, const KFrame& fr, float4* out, uint2* hit, unsigned long long* counters, bool pool,

@@ -54,7 +54,6 @@ static_assert(sizeof(LrlTriCold) == 32, "TriCold");
 struct KScene {
     const float4* recs;
     const uint4* node4;      // four-wide compressed nodes, 4 x uint4 each, indexed like recs (FAST lean kernel)
-    const float4* wide;      // 4-wide repack (lrl_wide.inc): 16 float4 per node
     const float4* triHot;
     const LrlTriCold* triCold;
     const LrlColor* materials;
@@ -116,14 +115,8 @@ enum { LRL_CTR_PRIMARY = 0, LRL_CTR_REFLECT, LRL_CTR_REFRACT, LRL_CTR_SHADOW, LR
 #ifndef LRL_LEAN_STACK
 #define LRL_LEAN_STACK 8          /* its LDS rows of parked children per lane (8 rows + 1: 32 waves per CU fit in 160 KB) */
 #endif
-#ifndef LRL_W4_WAVES
-#define LRL_W4_WAVES 6            /* __launch_bounds__ waves per SIMD of the 4-wide trace kernel */
-#endif
 #ifndef LRL_SWARM_CAP
 #define LRL_SWARM_CAP 1024         /* frontier entries of the wave-per-ray continuation kernel (LDS) */
-#endif
-#ifndef LRL_W4_STACK
-#define LRL_W4_STACK 24           /* stack entries per QUAD in LDS of the 4-wide trace kernel */
 #endif
 #define LRL_WF_SLOT_ALIGN (64u * LRL_WF_CHUNK_WORDS > 256u ? 64u * LRL_WF_CHUNK_WORDS : 256u)
 
@@ -180,10 +173,8 @@ struct WFrame {
 LRL_WF_DECLARE(lrl_parity)
 LRL_WF_DECLARE(lrl_fast)
 namespace lrl_fast {
-hipError_t wfLaunchTraceWide(const KScene& sc, const WFrame& wf, uint32_t raysPerQuad, hipStream_t stream);
 hipError_t wfLaunchTraceLean(const KScene& sc, const WFrame& wf, hipStream_t stream);
 hipError_t wfLaunchTraceSwarm(const KScene& sc, const WFrame& wf, hipStream_t stream);
-hipError_t wfLaunchWideFill(float4* wide, const float4* triHot, uint32_t slots, hipStream_t stream);
 }
 
 // kernels_parity.hip / kernels_fast.hip

@@ -44,8 +44,7 @@ struct LrlContext {
     // scene
     bool haveScene = false, haveCamera = false;
     LrlGeometryNum num{};
-    uint32_t nodeNum = 0, recNum = 0, bvhDepth = 0, wideNodes = 0, wideDepth = 0;
-    DevBuf wide;
+    uint32_t nodeNum = 0, recNum = 0, bvhDepth = 0;
     DevBuf nodes, nodes32, triHot, triCold, materials, spheres, circles, cylinders, cones, lights, tex, cube, triStage, matStage;
     uint32_t texW = 0, texH = 0, texL = 0, cubeSize = 0;
     std::vector<LrlColor> materialTable;
@@ -153,7 +152,6 @@ int validateBVH(LrlContext* c, const LrlSceneView* s, uint32_t& depthOut) {
 void fillKScene(const LrlContext* c, KScene& k) {
     k.recs = static_cast<const float4*>(c->nodes.p);
     k.node4 = static_cast<const uint4*>(c->nodes32.p);
-    k.wide = static_cast<const float4*>(c->wide.p);
     k.triHot = static_cast<const float4*>(c->triHot.p);
     k.triCold = static_cast<const LrlTriCold*>(c->triCold.p);
     k.materials = static_cast<const LrlColor*>(c->materials.p);
@@ -284,84 +282,6 @@ std::vector<uint4> buildNode4(const LrlSceneView* s, const std::vector<uint32_t>
     return out;
 }
 
-// 4-wide repack of the caller's binary tree for lrl_wide.inc: a node's items are its parked primitive and its children;
-// an inner child is replaced by ITS items while the node stays within four slots (largest box first).  Same boxes, same
-// leaves; triangle slots are filled with the hot records on the device (wideFillKernel).
-std::vector<float4> buildWide(const LrlSceneView* s, uint32_t& nodesOut, uint32_t& depthOut) {
-    const LrlBVHNode* bvh = s->bvh;
-    struct Item { bool inner; uint32_t ref; };      // inner: binary node index; else primitive (type << 28 | index)
-    auto primOf = [&](const LrlBVHNode& n) { return (uint32_t(n.geometry) << LRL_PRIM_TYPE_SHIFT) | (n.geometryNum & LRL_PRIM_INDEX_MASK); };
-    auto contents = [&](uint32_t b, Item* out) -> int {
-        const LrlBVHNode& n = bvh[b];
-        int k = 0;
-        if (n.geometry) out[k++] = {false, primOf(n)};
-        auto child = [&](uint32_t c) {
-            if (bvh[c].bound.leftChild) out[k++] = {true, c};
-            else if (bvh[c].geometry) out[k++] = {false, primOf(bvh[c])};
-        };
-        if (n.bound.leftChild) {
-            child(b + 1);
-            if (n.bound.rightChild) child(uint32_t(n.bound.rightChild));
-        }
-        return k;
-    };
-    auto area = [&](uint32_t b) {
-        const LrlBound& q = bvh[b].bound;
-        float dx = q.max[0] - q.min[0], dy = q.max[1] - q.min[1], dz = q.max[2] - q.min[2];
-        return dx * dy + dy * dz + dz * dx;
-    };
-    auto asf = [](uint32_t v) { float f; std::memcpy(&f, &v, 4); return f; };
-    std::vector<float4> wide(16, make_float4(0, 0, 0, 0));
-    struct Work { uint32_t bin, node, depth; };
-    std::vector<Work> work;
-    work.push_back({0u, 0u, 0u});
-    uint32_t depth = 0;
-    while (!work.empty()) {
-        const Work w = work.back();
-        work.pop_back();
-        depth = std::max(depth, w.depth);
-        Item items[8];
-        int n = contents(w.bin, items);
-        for (;;) {
-            int best = -1;
-            float bestArea = -1.0f;
-            Item sub[3];
-            for (int i = 0; i < n; ++i) {
-                if (!items[i].inner) continue;
-                const int add = contents(items[i].ref, sub);
-                if (n - 1 + add > 4) continue;
-                const float a = area(items[i].ref);
-                if (a > bestArea) { bestArea = a; best = i; }
-            }
-            if (best < 0) break;
-            const int add = contents(items[best].ref, sub);
-            for (int i = best; i + 1 < n; ++i) items[i] = items[i + 1];
-            --n;
-            for (int i = 0; i < add; ++i) items[n++] = sub[i];
-        }
-        for (int i = 0; i < n; ++i) {
-            float4* q = &wide[size_t(w.node) * 16 + size_t(i) * 4];      // re-taken every time: `wide` grows below
-            if (items[i].inner) {
-                const uint32_t child = uint32_t(wide.size() / 16);
-                wide.resize(wide.size() + 16, make_float4(0, 0, 0, 0));
-                q = &wide[size_t(w.node) * 16 + size_t(i) * 4];
-                const LrlBound& bb = bvh[items[i].ref].bound;
-                q[0] = make_float4(bb.min[0], bb.min[1], bb.min[2], 0);
-                q[1] = make_float4(bb.max[0], bb.max[1], bb.max[2], 0);
-                q[3] = make_float4(0, 0, asf(child), asf(1u));
-                work.push_back({items[i].ref, child, w.depth + 1});
-            } else if ((items[i].ref >> LRL_PRIM_TYPE_SHIFT) == 2u) {
-                q[3] = make_float4(0, 0, asf(items[i].ref & LRL_PRIM_INDEX_MASK), asf(2u));
-            } else {
-                q[3] = make_float4(0, 0, asf(items[i].ref), asf(3u));
-            }
-        }
-    }
-    nodesOut = uint32_t(wide.size() / 16);
-    depthOut = depth;
-    return wide;
-}
-
 // TrianglePre for [first, first+count): materials interned on the host, geometry on the device.
 int runTrianglePre(LrlContext* c, uint32_t first, uint32_t count, const LrlTriangle* tris) {
     if (!count) return LRL_OK;
@@ -378,8 +298,6 @@ int runTrianglePre(LrlContext* c, uint32_t first, uint32_t count, const LrlTrian
     if (rc) return rc;
     HIP_TRY(c, lrl_launch_triangle_pre(static_cast<const LrlTriangle*>(c->triStage.p), static_cast<const uint32_t*>(c->matStage.p), first,
                                        count, static_cast<float4*>(c->triHot.p), static_cast<LrlTriCold*>(c->triCold.p), c->stream));
-    if (c->wideNodes)   // the 4-wide nodes carry copies of the hot records
-        HIP_TRY(c, lrl_fast::wfLaunchWideFill(static_cast<float4*>(c->wide.p), static_cast<const float4*>(c->triHot.p), c->wideNodes * 4, c->stream));
     HIP_TRY(c, hipStreamSynchronize(c->stream));   // `mat` and the caller's array are borrowed only for this call
     return LRL_OK;
 }
@@ -414,7 +332,7 @@ int lrl_destroy(LrlContext* c) {
     if (!c) return LRL_ERR_INVALID_ARG;
     (void)hipSetDevice(c->device);
     (void)hipStreamSynchronize(c->stream);
-    for (DevBuf* b : {&c->wide, &c->nodes, &c->nodes32, &c->triHot, &c->triCold, &c->materials, &c->spheres, &c->circles, &c->cylinders, &c->cones, &c->lights,
+    for (DevBuf* b : {&c->nodes, &c->nodes32, &c->triHot, &c->triCold, &c->materials, &c->spheres, &c->circles, &c->cylinders, &c->cones, &c->lights,
                       &c->tex, &c->cube, &c->triStage, &c->matStage, &c->transDev, &c->outDev, &c->hitDev, &c->counterDev, &c->decayDev, &c->timelineDev, &c->wfArena})
         release(*b);
     for (auto& e : c->timingEvents) { (void)hipEventDestroy(e.first); (void)hipEventDestroy(e.second); }
@@ -493,17 +411,7 @@ int lrl_scene_upload(LrlContext* c, const LrlSceneView* s) {
         if (rc) return rc;
         HIP_TRY(c, hipStreamSynchronize(c->stream));
     }
-    {
-        c->wideNodes = 0;
-        uint32_t wn = 0, wd = 0;
-        std::vector<float4> wide = buildWide(s, wn, wd);
-        rc = upload(c, c->wide, wide.data(), wide.size() * sizeof(float4));
-        if (rc) return rc;
-        HIP_TRY(c, hipStreamSynchronize(c->stream));
-        c->wideDepth = wd;
-        c->wideNodes = wn;
-        if (std::getenv("LRL_DEBUG")) std::fprintf(stderr, "lrl: binary nodes %u (depth %u) -> 4-wide nodes %u (depth %u), compressed four-wide tree depth %u\n", s->bvhNodeNum, depth, wn, wd, c->node4Depth);
-    }
+    if (std::getenv("LRL_DEBUG")) std::fprintf(stderr, "lrl: binary nodes %u (depth %u), four-wide tree depth %u\n", s->bvhNodeNum, depth, c->node4Depth);
     c->materialTable.clear();
     c->materialIndex.clear();
     c->hasTransmission = false;
@@ -545,7 +453,6 @@ int lrl_scene_upload(LrlContext* c, const LrlSceneView* s) {
             if (rc) return rc;
             rc = upload(c, c->materials, c->materialTable.data(), c->materialTable.size() * sizeof(LrlColor));
             if (rc) return rc;
-            HIP_TRY(c, lrl_fast::wfLaunchWideFill(static_cast<float4*>(c->wide.p), static_cast<const float4*>(c->triHot.p), c->wideNodes * 4, c->stream));
             HIP_TRY(c, hipStreamSynchronize(c->stream));
         }
     }
@@ -671,25 +578,17 @@ static int renderWavefront(LrlContext* c, const LrlRenderParams* p, const KScene
     if (P64 * (1 + uint64_t(L)) >= (1ull << 31)) return fail(c, LRL_ERR_LIMIT, "pixels x (1 + lights) of one render exceeds 2^31 ray slots: render in row stripes");
     const size_t P = size_t(P64);
     const uint32_t words = uint32_t(P / 64), chunks = words * (1 + L) / LRL_WF_CHUNK_WORDS;
-    // FAST renders without counters trace the 4-wide repack with a quad per ray; PARITY and counting renders keep the reference's visit order
     // Trace kernel per iteration.  PARITY and counting renders: wfTraceKernel (the reference's visit order).  FAST: the lean
-    // one-lane-per-ray kernel, which hands rays that are still going after handoverTrips trips to the wave-per-ray kernel.
-    // LRL_TRACE / LRL_HYBRID_ITER / LRL_HANDOVER*: experiments (the 4-wide quad-per-ray kernel among them).
-    const char* which = std::getenv("LRL_TRACE");      // "ref" | "lean" (default) | "wide" | "wide1" | "hybrid"
-    const char* hyb = std::getenv("LRL_HYBRID_ITER");
+    // one-lane-per-ray kernel over the four-wide tree, which hands rays that are still going after handoverTrips trips to the
+    // wave-per-ray kernel.  LRL_TRACE=ref / LRL_HANDOVER*: diagnostics.
+    const char* which = std::getenv("LRL_TRACE");      // "ref": wfTraceKernel in FAST arithmetic
     const bool special = fast && !ctr && !(which && !std::strcmp(which, "ref"));
-    uint32_t leanIters = 0xffffffffu, wideR = 1;
-    if (special && which && !std::strcmp(which, "hybrid")) leanIters = hyb ? uint32_t(std::atoi(hyb)) : 2u;
-    if (special && which && !std::strcmp(which, "wide")) { leanIters = 0; wideR = 4; }
-    if (special && which && !std::strcmp(which, "wide1")) leanIters = 0;
-    const uint32_t wideNeed = 3 * c->wideDepth + 4;
-    const uint32_t ovfW = wideNeed > uint32_t(LRL_W4_STACK) ? wideNeed - uint32_t(LRL_W4_STACK) : 0u;
     // deepest stack: one parked child per level of the binary tree (wfTraceKernel), three per level of the four-wide tree (lean)
     const uint32_t stackNeed = special ? std::max(c->bvhDepth + 1, 3 * c->node4Depth + 4) : c->bvhDepth + 1;
     const uint32_t ldsRows = special ? uint32_t(LRL_LEAN_STACK) : uint32_t(LRL_WF_STACK);
     const uint32_t ovfN = stackNeed > ldsRows ? stackNeed - ldsRows : 0u;
     const size_t raysAll = P * (1 + size_t(L));
-    const size_t ovfBytes = std::max(size_t(chunks) * ovfN * 512, special ? (raysAll / 16) * ovfW * 128 : size_t(0));
+    const size_t ovfBytes = size_t(chunks) * ovfN * 512;
     const uint32_t refrEntries = c->hasTransmission ? p->maxDepth : 0u;
     // arena layout (every block 256-B aligned)
     size_t off = 0;
@@ -755,11 +654,7 @@ static int renderWavefront(LrlContext* c, const LrlRenderParams* p, const KScene
             ++c->timingUsed;
             HIP_TRY(c, hipEventRecord(a, stream));
         }
-        if (special && iter >= leanIters) {
-            WFrame w4 = wf;
-            w4.overflowEntries = ovfW;
-            HIP_TRY(c, lrl_fast::wfLaunchTraceWide(k, w4, wideR, stream));
-        } else if (special) {
+        if (special) {
             wf.contCount = contCounts + (iter < LRL_WF_MAX_ITERATIONS ? iter : 0);
             wf.handoverTrips = iter < 2 ? handoverEarly : handoverLate;   // few rays left after the first bounces: the waves are free sooner
             HIP_TRY(c, lrl_fast::wfLaunchTraceLean(k, wf, stream));
@@ -1003,7 +898,7 @@ int lrl_timing_end(LrlContext* c, double* totalMs, uint32_t* launches) {
 
 int lrl_scene_device_bytes(LrlContext* c, uint64_t out[4]) {
     if (!c || !out) return LRL_ERR_INVALID_ARG;
-    out[0] = uint64_t(c->recNum) * 64;
+    out[0] = uint64_t(c->recNum) * 128;      // binary records + four-wide compressed nodes, 64 B each per inner node
     out[1] = uint64_t(c->num.triangleNum) * 64;
     out[2] = uint64_t(c->num.triangleNum) * sizeof(LrlTriCold) + c->materialTable.size() * sizeof(LrlColor);
     out[3] = uint64_t(c->num.sphereNum + c->num.circleNum + c->num.cylinderNum + c->num.coneNum) * 128 + uint64_t(c->num.pointLightNum) * 32 +
