@@ -18,7 +18,10 @@ ONE sample of an N-sample jitter table (sample-index sharding, so per-GPU work i
 scaling) and the partial means are summed with one RCCL all-reduce per step, inside the timed
 region.  value = rays of all ranks / max-over-ranks time.
 
-  python bench.py [--gpus N] [--steps K] [--warmup W] [--mode fast|parity] [--builder reference|median]
+  python bench.py [--gpus N] [--steps K] [--warmup W] [--mode fast|parity] [--builder reference|median] [--workload c2|c3]
+
+--workload c3 measures SURVEY 8d's C3 (Pool demo scene, Pool shader variant, 64 spp, depth 8) the same way; it is not the
+headline line.
 """
 import argparse
 import json
@@ -42,7 +45,10 @@ def main():
     ap.add_argument("--subdivisions", type=int, default=2)
     ap.add_argument("--width", type=int, default=1920)
     ap.add_argument("--height", type=int, default=1080)
-    ap.add_argument("--depth", type=int, default=4)
+    ap.add_argument("--depth", type=int, default=0, help="RayTraceDepth (0 = the workload's own: 4 for c2, 8 for c3)")
+    ap.add_argument("--workload", default="c2", choices=["c2", "c3"],
+                    help="c2 (default, the headline metric's configuration) | c3: Pool demo scene, Pool shader variant, 64 spp (SURVEY 8d)")
+    ap.add_argument("--spp", type=int, default=0, help="samples per pixel (0 = the workload's own: 1 for c2, 64 for c3)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-rows", type=int, default=0, help="rows of the frame the CPU baseline renders (0 = auto)")
     a = ap.parse_args()
@@ -68,7 +74,11 @@ def main():
 
     # ---- scene: built on the host by the restated reference library, uploaded once ----
     t0 = time.time()
-    m = scenes.mesh_scene(subdivisions=a.subdivisions, builder=a.builder)
+    c3 = a.workload == "c3"
+    a.depth = a.depth or (8 if c3 else 4)
+    a.spp = a.spp or (64 if c3 else 1)
+    variant = abi.VARIANT_POOL if c3 else abi.VARIANT_BVH
+    m = scenes.pool(builder=a.builder) if c3 else scenes.mesh_scene(subdivisions=a.subdivisions, builder=a.builder)
     build_s = time.time() - t0
     info = m.bvh_info()
     W, H = a.width, a.height
@@ -81,18 +91,20 @@ def main():
     tr.set_camera(trans, W, H)
     tr.set_decay_origin((0, 0, 0, 1))
     mode = abi.MODE_FAST if a.mode == "fast" else abi.MODE_PARITY
-    jitter = host.jitter_table(world) if world > 1 else None
-    samples = (rank, rank + 1) if world > 1 else None
+    # every rank renders a.spp samples of an (a.spp * world)-entry jitter table: per-GPU work is fixed (weak scaling)
+    total_spp = a.spp * world
+    jitter = host.jitter_table(total_spp) if total_spp > 1 else None
+    samples = (rank * a.spp, (rank + 1) * a.spp) if world > 1 else None
 
     # ---- ray / node / primitive-test counts of this rank's frame (counting variant, un-timed) ----
-    _, _ = tr.render(max_depth=a.depth, mode=mode, counters=True, jitter=jitter, samples=samples, want_hits=False)
+    _, _ = tr.render(max_depth=a.depth, variant=variant, mode=mode, counters=True, jitter=jitter, samples=samples, want_hits=False)
     cn = tr.counters()
     rays, alg_bytes = cn.rays, cn.algorithmic_bytes()
 
     out = torch.empty((H, W, 4), dtype=torch.float32, device=dev)
 
     def step():
-        tr.render_device(out.data_ptr(), max_depth=a.depth, mode=mode, jitter=jitter, samples=samples)
+        tr.render_device(out.data_ptr(), max_depth=a.depth, variant=variant, mode=mode, jitter=jitter, samples=samples)
         if world > 1:
             tr.sync()                       # the library renders on its own stream; the collective runs on torch's
             dist.all_reduce(out, op=dist.ReduceOp.SUM)
@@ -120,7 +132,7 @@ def main():
     TRACE_FRAMES = 5
     tr.timing_begin()
     for _ in range(TRACE_FRAMES):
-        tr.render_device(out.data_ptr(), max_depth=a.depth, mode=mode, jitter=jitter, samples=samples, time_kernels=True)
+        tr.render_device(out.data_ptr(), max_depth=a.depth, variant=variant, mode=mode, jitter=jitter, samples=samples, time_kernels=True)
     tr.sync()
     trace_ms_total, trace_launches = tr.timing_end()
 
@@ -151,10 +163,11 @@ def main():
             "metric": "Mrays/s (whole node) at 1080p 4-bounce", "value": round(value, 2), "unit": "Mrays/s", "n_gpus": world,
             "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(ms_per_step, 4), "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": f"C2: Stanford bunny x{a.subdivisions} subdivisions ({view.num.triangleNum} triangles) + ground disc + 1 light, "
-                                   f"{W}x{H}, 1 spp per GPU, RayTraceDepth {a.depth}",
+            "config": {"workload": (f"C3: Pool demo scene ({view.num.triangleNum} triangles, water at rest), Pool shader variant, " if c3 else
+                                    f"C2: Stanford bunny x{a.subdivisions} subdivisions ({view.num.triangleNum} triangles) + ground disc + 1 light, ") +
+                                   f"{W}x{H}, {a.spp} spp per GPU, RayTraceDepth {a.depth}",
                        "bvh_builder": a.builder, "bvh_nodes": info["nodes"], "bvh_depth": info["max_depth"], "arithmetic": a.mode,
-                       "parallelism": "replicated scene, 1 sample index per GPU, RCCL all-reduce of the image" if world > 1 else "1 GPU",
+                       "parallelism": f"replicated scene, {a.spp} sample indices per GPU, RCCL all-reduce of the image" if world > 1 else "1 GPU",
                        "rays_per_frame": int(rays), "host_bvh_build_s": round(build_s, 2), "scene_upload_s": round(upload_s, 2),
                        "device_scene_bytes": dbytes},
             "roofline": {"bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
@@ -167,7 +180,7 @@ def main():
                                     "other_tests": int(cn.otherTests), "rays": int(rays)}},
         }
         if not a.no_cpu_baseline and world == 1:
-            line["cpu_baseline"] = cpu_baseline(a, m, view, trans, W, H)
+            line["cpu_baseline"] = cpu_baseline(a, m, view, trans, W, H, variant)
         print(json.dumps(line), flush=True)
     if world > 1:
         dist.barrier()
@@ -175,7 +188,7 @@ def main():
     tr.close()
 
 
-def cpu_baseline(a, m, view, trans, W, H):
+def cpu_baseline(a, m, view, trans, W, H, variant):
     """The CPU oracle (C++ restatement of the reference shader, OpenMP over rows) on a bounded stripe of the SAME frame."""
     from oracle import oracle_api as O
     cores = min(16, os.cpu_count() or 1)
@@ -185,14 +198,14 @@ def cpu_baseline(a, m, view, trans, W, H):
     rays, dt, reps = 0, 0.0, 0
     while dt < 12.0 or reps < 2:
         t0 = time.perf_counter()
-        _, _, c = O.render(view, trans, W, H, max_depth=a.depth, rows=(r0, r0 + rows), threads=cores, want_hits=False)
+        _, _, c = O.render(view, trans, W, H, max_depth=a.depth, variant=variant, rows=(r0, r0 + rows), threads=cores, want_hits=False)
         dt += time.perf_counter() - t0
         rays += c.rays
         reps += 1
         if reps >= 200:
             break
     return {"value": round(rays / dt / 1e6, 3), "unit": "Mrays/s", "cores": cores, "kind": "port",
-            "sample": f"rows {r0}..{r0 + rows} of the same {W}x{H} frame rendered {reps} times ({rays} rays, {dt:.1f} s), "
+            "sample": f"rows {r0}..{r0 + rows} of the same {W}x{H} frame (one sample per pixel) rendered {reps} times ({rays} rays, {dt:.1f} s), "
                       f"oracle/liboracle.so, OpenMP over rows"}
 
 

@@ -174,7 +174,7 @@ LRL_WF_DECLARE(lrl_parity)
 LRL_WF_DECLARE(lrl_fast)
 namespace lrl_fast {
 hipError_t wfLaunchTraceLean(const KScene& sc, const WFrame& wf, hipStream_t stream);
-hipError_t wfLaunchTraceSwarm(const KScene& sc, const WFrame& wf, hipStream_t stream);
+hipError_t wfLaunchTraceSwarm(const KScene& sc, const WFrame& wf, uint32_t waves, hipStream_t stream);
 }
 
 // kernels_parity.hip / kernels_fast.hip

@@ -58,6 +58,13 @@ struct LrlContext {
     DevBuf transDev, outDev, hitDev, counterDev, decayDev, timelineDev;
     DevBuf wfArena;                     // wavefront pipeline: path state, ray records, masks, refraction stacks, overflow stacks
     uint32_t* aliveHost = nullptr;      // pinned: per-iteration "any path alive" words copied back while the next iteration runs
+    // feedback for the hand-over thresholds of the FAST trace kernels: rays handed over per iteration of the last finished
+    // sample (pinned copy, read when its event has completed: never waited for)
+    uint32_t* contHost = nullptr;
+    hipEvent_t evCont = nullptr;
+    uint32_t contIters = 0;             // words of contHost in flight / ready
+    std::vector<uint32_t> handoverThr;  // per iteration index; empty until first use
+    std::vector<uint32_t> swarmGrid;    // waves launched for the handed-over rays of that iteration (a grid-stride kernel)
     hipEvent_t evIter[2] = {nullptr, nullptr};
     bool hasTransmission = false;       // some material has t != 0: refraction stacks are needed
     uint32_t lastIterations = 0;
@@ -337,6 +344,8 @@ int lrl_destroy(LrlContext* c) {
         release(*b);
     for (auto& e : c->timingEvents) { (void)hipEventDestroy(e.first); (void)hipEventDestroy(e.second); }
     if (c->aliveHost) (void)hipHostFree(c->aliveHost);
+    if (c->contHost) (void)hipHostFree(c->contHost);
+    if (c->evCont) (void)hipEventDestroy(c->evCont);
     for (hipEvent_t e : c->evIter) if (e) (void)hipEventDestroy(e);
     if (c->evStart) (void)hipEventDestroy(c->evStart);
     if (c->evStop) (void)hipEventDestroy(c->evStop);
@@ -569,6 +578,7 @@ int lrl_compute_decay_origin(LrlContext* c, uint32_t variant, LrlDecayOrigin* ou
 
 // ---- wavefront pipeline: generate, then (trace, shade) per ray segment until no path is alive ----
 #define LRL_WF_MAX_ITERATIONS 4096u
+#define LRL_FEEDBACK_ITERS 64u
 static int renderWavefront(LrlContext* c, const LrlRenderParams* p, const KScene& k, KFrame f, float* rgbaDev, uint32_t* hitDev,
                            unsigned long long* ctr, hipStream_t stream, uint32_t rows, hipEvent_t e0, hipEvent_t e1) {
     const bool fast = p->mode == LRL_MODE_FAST, pool = p->variant == LRL_VARIANT_POOL;
@@ -604,6 +614,8 @@ static int renderWavefront(LrlContext* c, const LrlRenderParams* p, const KScene
         HIP_TRY(c, hipHostMalloc(reinterpret_cast<void**>(&c->aliveHost), LRL_WF_MAX_ITERATIONS * 4, hipHostMallocDefault));
         HIP_TRY(c, hipEventCreateWithFlags(&c->evIter[0], hipEventDisableTiming));
         HIP_TRY(c, hipEventCreateWithFlags(&c->evIter[1], hipEventDisableTiming));
+        HIP_TRY(c, hipHostMalloc(reinterpret_cast<void**>(&c->contHost), LRL_FEEDBACK_ITERS * 4, hipHostMallocDefault));
+        HIP_TRY(c, hipEventCreateWithFlags(&c->evCont, hipEventDisableTiming));
     }
     char* base = static_cast<char*>(c->wfArena.p);
     WFrame wf{};
@@ -624,6 +636,32 @@ static int renderWavefront(LrlContext* c, const LrlRenderParams* p, const KScene
     const char* ho = std::getenv("LRL_HANDOVER");
     const char* hoLate = std::getenv("LRL_HANDOVER_LATE");
     const uint32_t handoverEarly = ho ? uint32_t(std::atoi(ho)) : 64u, handoverLate = hoLate ? uint32_t(std::atoi(hoLate)) : 32u;
+    // The hand-over pays while the long rays are few.  Where most rays are long (Pool: flat tree of tall boxes) the slots
+    // run out and the wave-per-ray kernel becomes the slow part, so the threshold of an iteration follows the number of rays
+    // that iteration handed over in the last finished sample: doubled (x4 when far beyond the slots) while (nearly) all
+    // slots were asked for, halved back towards its default below 1/8.  LRL_ADAPT=0 pins the defaults.
+    const bool adapt = !(std::getenv("LRL_ADAPT") && std::atoi(std::getenv("LRL_ADAPT")) == 0);
+    auto baseThr = [&](uint32_t i) { return i < 2 ? handoverEarly : handoverLate; };   // few rays left after the first bounces: the waves are free sooner
+    if (c->handoverThr.empty() || !adapt) {
+        c->handoverThr.resize(LRL_FEEDBACK_ITERS);
+        for (uint32_t i = 0; i < LRL_FEEDBACK_ITERS; ++i) c->handoverThr[i] = baseThr(i);
+        c->swarmGrid.assign(LRL_FEEDBACK_ITERS, contSlots);
+    }
+    auto feedback = [&]() {
+        if (!adapt || !c->contIters || hipEventQuery(c->evCont) != hipSuccess) return;
+        for (uint32_t i = 0; i < c->contIters; ++i) {
+            uint32_t& t = c->handoverThr[i];
+            const uint32_t asked = c->contHost[i];
+            if (t == 0) continue;
+            if (asked > 4 * 65536u) t = std::min(t * 4, 4096u);
+            else if (asked > 60000u) t = std::min(t * 2, 4096u);
+            else if (asked < 8192u && t > baseThr(i)) t = std::max(baseThr(i), t / 2);
+            // dispatching 65536 workgroups that find nothing costs ~15 us a launch: twice what was asked for last time is
+            // plenty (the kernel strides over the slots whatever the grid)
+            c->swarmGrid[i] = std::min(contSlots, std::max(2048u, (2 * asked + 1023u) / 1024u * 1024u));
+        }
+        c->contIters = 0;
+    };
     wf.handoverTrips = handoverEarly;
     wf.contSlots = contSlots; wf.contStride = contStride;
     wf.contHead = reinterpret_cast<uint4*>(base + oContHead);
@@ -656,9 +694,9 @@ static int renderWavefront(LrlContext* c, const LrlRenderParams* p, const KScene
         }
         if (special) {
             wf.contCount = contCounts + (iter < LRL_WF_MAX_ITERATIONS ? iter : 0);
-            wf.handoverTrips = iter < 2 ? handoverEarly : handoverLate;   // few rays left after the first bounces: the waves are free sooner
+            wf.handoverTrips = c->handoverThr[std::min(iter, LRL_FEEDBACK_ITERS - 1)];
             HIP_TRY(c, lrl_fast::wfLaunchTraceLean(k, wf, stream));
-            if (wf.handoverTrips) HIP_TRY(c, lrl_fast::wfLaunchTraceSwarm(k, wf, stream));
+            if (wf.handoverTrips) HIP_TRY(c, lrl_fast::wfLaunchTraceSwarm(k, wf, c->swarmGrid[std::min(iter, LRL_FEEDBACK_ITERS - 1)], stream));
         }
         else HIP_TRY(c, fast ? lrl_fast::wfLaunchTrace(k, wf, stream) : lrl_parity::wfLaunchTrace(k, wf, stream));
         if (b) HIP_TRY(c, hipEventRecord(b, stream));
@@ -676,6 +714,7 @@ static int renderWavefront(LrlContext* c, const LrlRenderParams* p, const KScene
     uint32_t iterations = 0;
     for (uint32_t s = f.sampleBegin; s < f.sampleEnd; ++s) {
         wf.sample = s;
+        if (special) feedback();
         HIP_TRY(c, hipMemsetAsync(wf.alive, 0, size_t(LRL_WF_MAX_ITERATIONS) * 4 + size_t(bound) * 4, stream));
         HIP_TRY(c, fast ? lrl_fast::wfLaunchGenerate(k, f, wf, stream) : lrl_parity::wfLaunchGenerate(k, f, wf, stream));
         uint32_t iter = 0;
@@ -698,12 +737,17 @@ static int renderWavefront(LrlContext* c, const LrlRenderParams* p, const KScene
             if (c->aliveHost[bound - 1] != 0) return fail(c, LRL_ERR_LIMIT, "wavefront pipeline did not finish within its iteration bound");
         }
         iterations += iter;
+        if (special && adapt && c->contIters == 0) {      // (a copy still in flight is left alone)
+            c->contIters = std::min(iter, LRL_FEEDBACK_ITERS);
+            HIP_TRY(c, hipMemcpyAsync(c->contHost, contCounts, size_t(c->contIters) * 4, hipMemcpyDeviceToHost, stream));
+            HIP_TRY(c, hipEventRecord(c->evCont, stream));
+        }
         if (std::getenv("LRL_DEBUG") && special) {
             std::vector<uint32_t> cc(iter);
             HIP_TRY(c, hipStreamSynchronize(stream));
             HIP_TRY(c, hipMemcpy(cc.data(), contCounts, iter * 4, hipMemcpyDeviceToHost));
-            std::fprintf(stderr, "lrl: handed-over rays per iteration (threshold %u):", wf.handoverTrips);
-            for (uint32_t v : cc) std::fprintf(stderr, " %u", v);
+            std::fprintf(stderr, "lrl: handed-over rays per iteration (threshold):");
+            for (uint32_t i = 0; i < iter; ++i) std::fprintf(stderr, " %u (%u)", cc[i], c->handoverThr[std::min(i, LRL_FEEDBACK_ITERS - 1)]);
             std::fprintf(stderr, "\n");
         }
     }
