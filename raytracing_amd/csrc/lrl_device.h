@@ -137,9 +137,7 @@ struct WFrame {
     uint32_t xcdBlock;       // lean trace kernel: edge (in tiles) of the square pixel blocks dealt out to the 8 XCDs; 0 = workgroup i takes word i
     float4* answer;          // xyz accumulated colour, w = v of the pending light terms
     float4* ratio;           // ratioNow
-    float4* decay;           // decayNow
-    float4* rayO;            // ray of the segment in flight (origin, direction)
-    float4* rayD;
+    float4* decay;           // decayNow (kept only when a material transmits: otherwise it never leaves decayOrigin)
     float4* hit;             // closest-hit result of the segment in flight: t, primitive bits, aux
     float4* pendA;           // pending light terms: diffuse colour, texD
     float4* pendB;           //                      ratio at the hit, u

@@ -603,7 +603,7 @@ static int renderWavefront(LrlContext* c, const LrlRenderParams* p, const KScene
     // arena layout (every block 256-B aligned)
     size_t off = 0;
     auto take = [&](size_t bytes) { size_t o = off; off += (bytes + 255) / 256 * 256; return o; };
-    const size_t oState = take(P * 16 * 8), oFlags = take(P * 4), oRayQ = take(P * (1 + size_t(L)) * 32), oMaskC = take(size_t(words) * 8),
+    const size_t oState = take(P * 16 * 6), oFlags = take(P * 4), oRayQ = take(P * (1 + size_t(L)) * 32), oMaskC = take(size_t(words) * 8),
                  oMaskS = take(size_t(words) * 8), oRefr = take(P * 64 * refrEntries), oOvf = take(ovfBytes),
                  oAlive = take(LRL_WF_MAX_ITERATIONS * 4 * 2);
     const uint32_t contSlots = 65536, contStride = stackNeed + 1;
@@ -623,8 +623,8 @@ static int renderWavefront(LrlContext* c, const LrlRenderParams* p, const KScene
     const char* xcd = std::getenv("LRL_XCD_BLOCK");
     wf.xcdBlock = xcd ? uint32_t(std::atoi(xcd)) : 0u;
     float4* st = reinterpret_cast<float4*>(base + oState);
-    wf.answer = st; wf.ratio = st + P; wf.decay = st + 2 * P; wf.rayO = st + 3 * P; wf.rayD = st + 4 * P; wf.hit = st + 5 * P;
-    wf.pendA = st + 6 * P; wf.pendB = st + 7 * P;
+    wf.answer = st; wf.ratio = st + P; wf.decay = st + 2 * P; wf.hit = st + 3 * P;
+    wf.pendA = st + 4 * P; wf.pendB = st + 5 * P;
     wf.flags = reinterpret_cast<uint32_t*>(base + oFlags);
     wf.rayQ = reinterpret_cast<float4*>(base + oRayQ);
     wf.maskC = reinterpret_cast<unsigned long long*>(base + oMaskC);
