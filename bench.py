@@ -48,6 +48,7 @@ def main():
     ap.add_argument("--depth", type=int, default=0, help="RayTraceDepth (0 = the workload's own: 4 for c2, 8 for c3)")
     ap.add_argument("--workload", default="c2", choices=["c2", "c3"],
                     help="c2 (default, the headline metric's configuration) | c3: Pool demo scene, Pool shader variant, 64 spp (SURVEY 8d)")
+    ap.add_argument("--grid", type=int, default=1, help="c2 only: grid x grid replicated copies of the mesh (towards C5: 9 -> 100.5 M triangles)")
     ap.add_argument("--spp", type=int, default=0, help="samples per pixel (0 = the workload's own: 1 for c2, 64 for c3)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-rows", type=int, default=0, help="rows of the frame the CPU baseline renders (0 = auto)")
@@ -78,7 +79,7 @@ def main():
     a.depth = a.depth or (8 if c3 else 4)
     a.spp = a.spp or (64 if c3 else 1)
     variant = abi.VARIANT_POOL if c3 else abi.VARIANT_BVH
-    m = scenes.pool(builder=a.builder) if c3 else scenes.mesh_scene(subdivisions=a.subdivisions, builder=a.builder)
+    m = scenes.pool(builder=a.builder) if c3 else scenes.mesh_scene(subdivisions=a.subdivisions, builder=a.builder, grid=a.grid)
     build_s = time.time() - t0
     info = m.bvh_info()
     W, H = a.width, a.height
@@ -164,7 +165,7 @@ def main():
             "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(ms_per_step, 4), "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": (f"C3: Pool demo scene ({view.num.triangleNum} triangles, water at rest), Pool shader variant, " if c3 else
-                                    f"C2: Stanford bunny x{a.subdivisions} subdivisions ({view.num.triangleNum} triangles) + ground disc + 1 light, ") +
+                                    f"C2: Stanford bunny x{a.subdivisions} subdivisions{f', {a.grid}x{a.grid} copies' if a.grid > 1 else ''} ({view.num.triangleNum} triangles) + ground disc + 1 light, ") +
                                    f"{W}x{H}, {a.spp} spp per GPU, RayTraceDepth {a.depth}",
                        "bvh_builder": a.builder, "bvh_nodes": info["nodes"], "bvh_depth": info["max_depth"], "arithmetic": a.mode,
                        "parallelism": f"replicated scene, {a.spp} sample indices per GPU, RCCL all-reduce of the image" if world > 1 else "1 GPU",

@@ -149,6 +149,23 @@ int lrl_last_kernel_ms(LrlContext* ctx, float* ms);
 #define LRL_MAX_TIMED_LAUNCHES 4096u
 int lrl_timing_begin(LrlContext* ctx);
 int lrl_timing_end(LrlContext* ctx, double* total_ms, uint32_t* launches);
+/* ---- Pool water simulation (replaces WaterSimulation of /root/reference/Pool/Pool.cpp:46-235 and the
+ * shaders Pool/shaders/WaterAccelerationCompute0.cpp, WaterPositionCompute0.cpp, WaterPositionSyncCompute0.cpp) ----
+ * The water is a gx x gy grid of points (Pool/Pool.cpp:84-90, buffer binding 10); its 2 (gx-1) (gy-1) triangles are
+ * triangles [firstTriangle, ...) of the uploaded scene (the reference keeps them at the head, :128-129).
+ * lrl_water_init   = water.dataInit() (:236-239): points and parameters {k, dt} (UBO 4) to the device, plus the origin
+ *                    records of the water triangles (the sync writes their corner heights; `triangles` = the same records
+ *                    that were uploaded with the scene, borrowed during the call).
+ * lrl_water_step   = WaterSimulation::run() (:224-235): n x (acceleration, position), then the position sync, followed by
+ *                    TrianglePre of the water triangles (what model.upToDate + tracerInit.run() do next, :654-655); all
+ *                    enqueued on the context's stream, no host wait.  n = 0 only syncs (the reference's init, :649-650).
+ * lrl_water_read   : points and / or the water triangles' origin records back to the host (tests; either may be NULL).
+ * gx * gy <= 16384.  Results are bit-identical to the reference's shaders (tests/test_gpu_parity.py). */
+int lrl_water_init(LrlContext* ctx, uint32_t gx, uint32_t gy, float k, float dt, const LrlWaterPoint* points,
+                   uint32_t firstTriangle, const LrlTriangle* triangles);
+int lrl_water_step(LrlContext* ctx, uint32_t substeps);
+int lrl_water_read(LrlContext* ctx, LrlWaterPoint* points, LrlTriangle* triangles);
+
 /* device memory held for the scene (bytes), by class: nodes (binary records + four-wide nodes), triangle hot,
  * triangle cold, other */
 int lrl_scene_device_bytes(LrlContext* ctx, uint64_t out[4]);

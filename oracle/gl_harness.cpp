@@ -277,10 +277,44 @@ static int probeMain(Args const& a) {
     return 0;
 }
 
+// The reference's water simulation (Pool/Pool.cpp:224-235): n x (WaterAcceleration, WaterPosition), then WaterPositionSync,
+// on the reference's own compute shaders.  --water: gx*gy points of 16 B {z, v, a, blank}; --tris: trianglesOrigin (160 B).
+static int waterMain(Args const& a) {
+    initGL(16, 16);
+    std::string dir = std::string(a.get("--shaders")) + "/";
+    std::vector<uint8_t> water = readBin(a.get("--water")), tris = readBin(a.get("--tris"));
+    const GLuint groupsX = GLuint(atoi(a.get("--groups", 1))), groupsY = GLuint(atoi(a.get("--groups", 2)));
+    const int steps = atoi(a.get("--steps"));
+    float para[4] = {float(atof(a.get("--k"))), float(atof(a.get("--dt"))), 0, 0};
+    if (water.size() != size_t(groupsX) * 8 * groupsY * 8 * 16) die("water: --water must hold (8 groupsX) x (8 groupsY) points of 16 bytes");
+    GLuint acc = link({compile(GL_COMPUTE_SHADER, readText(dir + "WaterAccelerationCompute0.cpp"), "WaterAcceleration")}, "WaterAcceleration");
+    GLuint pos = link({compile(GL_COMPUTE_SHADER, readText(dir + "WaterPositionCompute0.cpp"), "WaterPosition")}, "WaterPosition");
+    GLuint sync = link({compile(GL_COMPUTE_SHADER, readText(dir + "WaterPositionSyncCompute0.cpp"), "WaterPositionSync")}, "WaterPositionSync");
+    makeBuffer(GL_UNIFORM_BUFFER, 4, para, 16);                                            // Pool/Pool.cpp:484 {4, 10}
+    GLuint triBuf = makeBuffer(GL_SHADER_STORAGE_BUFFER, 1, tris.data(), tris.size());
+    GLuint waterBuf = makeBuffer(GL_SHADER_STORAGE_BUFFER, 10, water.data(), water.size());
+    for (int i = 0; i < steps; ++i) {
+        glUseProgram_(acc); glDispatchCompute_(groupsX, groupsY, 1); glMemoryBarrier_(GL_SHADER_STORAGE_BARRIER_BIT);
+        glUseProgram_(pos); glDispatchCompute_(groupsX, groupsY, 1); glMemoryBarrier_(GL_SHADER_STORAGE_BARRIER_BIT);
+    }
+    glUseProgram_(sync); glDispatchCompute_(groupsX, groupsY, 1); glMemoryBarrier_(GL_ALL_BARRIER_BITS);
+    glFinish_();
+    glBindBuffer_(GL_SHADER_STORAGE_BUFFER, waterBuf);
+    glGetBufferSubData_(GL_SHADER_STORAGE_BUFFER, 0, GLsizeiptr(water.size()), water.data());
+    glBindBuffer_(GL_SHADER_STORAGE_BUFFER, triBuf);
+    glGetBufferSubData_(GL_SHADER_STORAGE_BUFFER, 0, GLsizeiptr(tris.size()), tris.data());
+    writeBin(a.get("--water-out"), water.data(), water.size());
+    writeBin(a.get("--tri-out"), tris.data(), tris.size());
+    GLenum e = glGetError_();
+    if (e) fprintf(stderr, "gl_harness: GL error 0x%x\n", e);
+    return 0;
+}
+
 int main(int argc, char** argv) {
     Args a; for (int i = 1; i < argc; ++i) a.v.push_back(argv[i]);
-    if (a.v.empty()) die("usage: gl_harness render|probe ...");
+    if (a.v.empty()) die("usage: gl_harness render|probe|water ...");
     if (a.v[0] == "probe") return probeMain(a);
+    if (a.v[0] == "water") return waterMain(a);
     if (a.v[0] != "render") die("unknown mode");
     const char* shaderDir = a.get("--shaders");
     const char* scenePath = a.get("--scene");

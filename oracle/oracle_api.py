@@ -63,6 +63,23 @@ def decay_origin(view, trans, variant=abi.VARIANT_BVH):
     return out[0]
 
 
+def water_run(points, gx, gy, k, dt, substeps):
+    """n x (WaterAcceleration, WaterPosition) on a copy of `points` (abi.WATER_POINT[gx*gy]) -> new points"""
+    w = np.ascontiguousarray(points, dtype=abi.WATER_POINT).copy()
+    assert w.shape[0] == gx * gy
+    lib().oracle_water_run(w.ctypes.data_as(C.c_void_p), C.c_uint32(gx), C.c_uint32(gy), C.c_float(k), C.c_float(dt), C.c_uint32(substeps))
+    return w
+
+
+def water_sync(points, gx, gy, tris):
+    """WaterPositionSync on a copy of `tris` (abi.TRIANGLE[>= 2*(gx-1)*(gy-1)]) -> new triangles"""
+    w = np.ascontiguousarray(points, dtype=abi.WATER_POINT)
+    t = np.ascontiguousarray(tris, dtype=abi.TRIANGLE).copy()
+    assert w.shape[0] == gx * gy and t.shape[0] >= 2 * (gx - 1) * (gy - 1)
+    lib().oracle_water_sync(w.ctypes.data_as(C.c_void_p), C.c_uint32(gx), C.c_uint32(gy), t.ctypes.data_as(C.c_void_p))
+    return t
+
+
 # ---- the reference itself, on llvmpipe -----------------------------------------------------------
 def harness_available(shader_dir):
     return os.path.exists(HARNESS) and os.path.isdir(shader_dir) and os.path.exists("/usr/lib/x86_64-linux-gnu/dri/swrast_dri.so")
@@ -109,3 +126,19 @@ def run_reference(host_model, trans, width, height, shader_dir, max_depth=None, 
             out["tri"] = np.fromfile(os.path.join(td, "tri.bin"), dtype=abi.TRIANGLE_GPU)
             out["circles"] = np.fromfile(os.path.join(td, "circle.bin"), dtype=abi.CIRCLE)
         return out
+
+
+def run_reference_water(points, gx, gy, k, dt, substeps, tris, shader_dir):
+    """The reference's three water compute shaders on llvmpipe: substeps x (acceleration, position), then sync.
+    -> (points, triangles) after the run"""
+    w = np.ascontiguousarray(points, dtype=abi.WATER_POINT)
+    t = np.ascontiguousarray(tris, dtype=abi.TRIANGLE)
+    with tempfile.TemporaryDirectory() as td:
+        wf, tf, wo, to = (os.path.join(td, n) for n in ("w.bin", "t.bin", "wo.bin", "to.bin"))
+        w.tofile(wf); t.tofile(tf)
+        cmd = [HARNESS, "water", "--shaders", shader_dir, "--water", wf, "--tris", tf, "--groups", str(gx // 8), str(gy // 8),
+               "--steps", str(substeps), "--k", repr(float(k)), "--dt", repr(float(dt)), "--water-out", wo, "--tri-out", to]
+        r = subprocess.run(cmd, capture_output=True, text=True)
+        if r.returncode != 0:
+            raise RuntimeError("gl_harness water failed:\n" + r.stderr[-4000:])
+        return np.fromfile(wo, dtype=abi.WATER_POINT), np.fromfile(to, dtype=abi.TRIANGLE)

@@ -770,4 +770,51 @@ int oracle_decay_origin(const LrlSceneView* sv, const LrlTrans* trans, uint32_t 
     return 0;
 }
 
+
+// ---- Pool water simulation (next row f2) ----
+// One substep = WaterAccelerationCompute0.cpp:22-41 then WaterPositionCompute0.cpp:49-55, in the shaders' expression order
+// (this file is compiled without contraction).  The acceleration pass reads z of its neighbours and writes only a, the
+// position pass is point-local, so sweeping the grid in place is the same as the two dispatches.  gx = gl_NumWorkGroups.x * 8
+// (row length), gy = gl_NumWorkGroups.y * 8; the shader strides rows by gx in `index` but reaches its y neighbours with
+// gy (`offset`, :33): kept as it is (the reference only uses square grids).
+struct OracleWaterPoint { float z, v, a, blank; };
+void oracle_water_run(OracleWaterPoint* w, uint32_t gx, uint32_t gy, float k, float dt, uint32_t substeps) {
+    for (uint32_t s = 0; s < substeps; ++s) {
+        for (uint32_t y = 0; y < gy; ++y)
+            for (uint32_t x = 0; x < gx; ++x) {
+                float dv = 0;
+                const uint32_t index = x + gx * y;
+                if (x != 0 && x != gx - 1) dv += 2 * w[index].z - w[index - 1].z - w[index + 1].z;
+                else if (x != 0) dv += w[index].z - w[index - 1].z;
+                else dv += w[index].z - w[index + 1].z;
+                const uint32_t offset = gy;
+                if (y != 0 && y != offset - 1) dv += 2 * w[index].z - w[index - offset].z - w[index + offset].z;
+                else if (y != 0) dv += w[index].z - w[index - offset].z;
+                else dv += w[index].z - w[index + offset].z;
+                w[index].a = k * dt * dv;
+            }
+        for (uint32_t i = 0; i < gx * gy; ++i) {
+            w[i].z -= dt * (w[i].v + w[i].a / 2);
+            w[i].v += w[i].a;
+            w[i].v *= 0.999985f;
+        }
+    }
+}
+// WaterPositionSyncCompute0.cpp:49-75: the height of point (x, y) goes into the up to six triangle corners that share it
+void oracle_water_sync(const OracleWaterPoint* w, uint32_t gx, uint32_t gy, LrlTriangle* tris) {
+    for (uint32_t y = 0; y < gy; ++y)
+        for (uint32_t x = 0; x < gx; ++x) {
+            const float z = w[x + gx * y].z;
+            const uint32_t t = x + y * 2 * (gx - 1);
+            if (x != 0) {
+                if (y != 0) tris[t - gx].p1[2] = z;
+                if (y != gy - 1) { tris[t - 1].p2[2] = z; tris[t + gx - 2].p3[2] = z; }
+            }
+            if (x != gx - 1) {
+                if (y != 0) { tris[t - 2 * (gx - 1)].p3[2] = z; tris[t - gx + 1].p2[2] = z; }
+                if (y != gy - 1) tris[t].p1[2] = z;
+            }
+        }
+}
+
 }  // extern "C"

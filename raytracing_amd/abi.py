@@ -101,3 +101,7 @@ def scene_view_arrays(view):
         "bvh": arr(view.bvh, view.bvhNodeNum, BVHNODE),
     }
     return out
+
+# Pool water simulation point (Pool/Pool.cpp:84-90)
+WATER_POINT = np.dtype([("z", "<f4"), ("v", "<f4"), ("a", "<f4"), ("blank", "<f4")])
+assert WATER_POINT.itemsize == 16

@@ -46,7 +46,86 @@ __global__ __launch_bounds__(256) void circlePreKernel(LrlCircle* __restrict__ c
     q[2] = make_float4(e1.x, e1.y, e1.z, e.w);
 }
 
+// ---- Pool water simulation: /root/reference/Pool/shaders/WaterAccelerationCompute0.cpp:22-41,
+// WaterPositionCompute0.cpp:49-55, WaterPositionSyncCompute0.cpp:49-75, driven as Pool/Pool.cpp:224-235 ----
+// The reference dispatches 2 * n + 1 tiny grids per frame (n = 200: 401 launches for 2304 points).  Here ONE workgroup keeps
+// the heights in LDS and runs all n substeps between barriers, then scatters the heights into the corners of the water
+// triangles (device copy of their origin records); TrianglePre of those triangles follows as a second launch.
+// Same expressions in the same order, no contraction (this translation unit): bit-identical to the shaders on llvmpipe.
+#define LRL_WATER_THREADS 1024u
+#define LRL_WATER_MAX_POINTS 16384u          /* 64 KB of LDS */
+__global__ __launch_bounds__(LRL_WATER_THREADS) void waterRunKernel(float4* __restrict__ water, uint32_t gx, uint32_t gy, float k, float dt,
+                                                                  uint32_t substeps, LrlTriangle* __restrict__ tris) {
+    extern __shared__ float zs[];
+    const uint32_t n = gx * gy;
+    for (uint32_t i = threadIdx.x; i < n; i += LRL_WATER_THREADS) zs[i] = water[i].x;
+    __syncthreads();
+    // every thread owns the points threadIdx.x + j * 1024; their v and a stay in registers
+    constexpr uint32_t OWN = LRL_WATER_MAX_POINTS / LRL_WATER_THREADS;
+    float v[OWN], acc[OWN];
+#pragma unroll
+    for (uint32_t j = 0; j < OWN; ++j) {
+        const uint32_t i = threadIdx.x + j * LRL_WATER_THREADS;
+        v[j] = i < n ? water[i].y : 0.0f;
+        acc[j] = i < n ? water[i].z : 0.0f;
+    }
+    for (uint32_t s = 0; s < substeps; ++s) {
+#pragma unroll
+        for (uint32_t j = 0; j < OWN; ++j) {
+            const uint32_t index = threadIdx.x + j * LRL_WATER_THREADS;
+            if (index < n) {
+                const uint32_t x = index % gx, y = index / gx;
+                float dv = 0;
+                if (x != 0 && x != gx - 1) dv += 2 * zs[index] - zs[index - 1] - zs[index + 1];
+                else if (x != 0) dv += zs[index] - zs[index - 1];
+                else dv += zs[index] - zs[index + 1];
+                const uint32_t offset = gy;                      // the shader's row stride for the y neighbours (:33)
+                if (y != 0 && y != offset - 1) dv += 2 * zs[index] - zs[index - offset] - zs[index + offset];
+                else if (y != 0) dv += zs[index] - zs[index - offset];
+                else dv += zs[index] - zs[index + offset];
+                acc[j] = k * dt * dv;
+            }
+        }
+        __syncthreads();                                         // every acceleration of this substep has read its neighbours
+#pragma unroll
+        for (uint32_t j = 0; j < OWN; ++j) {
+            const uint32_t index = threadIdx.x + j * LRL_WATER_THREADS;
+            if (index < n) {
+                zs[index] -= dt * (v[j] + acc[j] / 2);
+                v[j] += acc[j];
+                v[j] *= 0.999985f;
+            }
+        }
+        __syncthreads();
+    }
+#pragma unroll
+    for (uint32_t j = 0; j < OWN; ++j) {
+        const uint32_t index = threadIdx.x + j * LRL_WATER_THREADS;
+        if (index < n) {
+            const float z = zs[index];
+            water[index] = make_float4(z, v[j], acc[j], water[index].w);
+            if (tris) {                                          // WaterPositionSync: each corner is written by exactly one point
+                const uint32_t x = index % gx, y = index / gx;
+                const uint32_t t = x + y * 2 * (gx - 1);
+                if (x != 0) {
+                    if (y != 0) tris[t - gx].p1[2] = z;
+                    if (y != gy - 1) { tris[t - 1].p2[2] = z; tris[t + gx - 2].p3[2] = z; }
+                }
+                if (x != gx - 1) {
+                    if (y != 0) { tris[t - 2 * (gx - 1)].p3[2] = z; tris[t - gx + 1].p2[2] = z; }
+                    if (y != gy - 1) tris[t].p1[2] = z;
+                }
+            }
+        }
+    }
+}
+
 }  // namespace lrl_parity
+
+hipError_t lrl_launch_water_run(float4* water, uint32_t gx, uint32_t gy, float k, float dt, uint32_t substeps, LrlTriangle* tris, hipStream_t stream) {
+    hipLaunchKernelGGL(lrl_parity::waterRunKernel, dim3(1), dim3(LRL_WATER_THREADS), size_t(gx) * gy * 4, stream, water, gx, gy, k, dt, substeps, tris);
+    return hipGetLastError();
+}
 
 static size_t ldsBytes(const KFrame& fr) { return size_t(fr.stackEntries) * LRL_BLOCK_THREADS * 8; }
 static dim3 gridFor(const KFrame& fr) {

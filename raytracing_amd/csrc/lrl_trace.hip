@@ -45,6 +45,9 @@ struct LrlContext {
     bool haveScene = false, haveCamera = false;
     LrlGeometryNum num{};
     uint32_t nodeNum = 0, recNum = 0, bvhDepth = 0;
+    DevBuf waterPoints, waterTris, waterMat;   // Pool water simulation (lrl_water_*)
+    uint32_t waterGX = 0, waterGY = 0, waterFirst = 0;
+    float waterK = 0, waterDt = 0;
     DevBuf nodes, nodes32, triHot, triCold, materials, spheres, circles, cylinders, cones, lights, tex, cube, triStage, matStage;
     uint32_t texW = 0, texH = 0, texL = 0, cubeSize = 0;
     std::vector<LrlColor> materialTable;
@@ -339,7 +342,7 @@ int lrl_destroy(LrlContext* c) {
     if (!c) return LRL_ERR_INVALID_ARG;
     (void)hipSetDevice(c->device);
     (void)hipStreamSynchronize(c->stream);
-    for (DevBuf* b : {&c->nodes, &c->nodes32, &c->triHot, &c->triCold, &c->materials, &c->spheres, &c->circles, &c->cylinders, &c->cones, &c->lights,
+    for (DevBuf* b : {&c->waterPoints, &c->waterTris, &c->waterMat, &c->nodes, &c->nodes32, &c->triHot, &c->triCold, &c->materials, &c->spheres, &c->circles, &c->cylinders, &c->cones, &c->lights,
                       &c->tex, &c->cube, &c->triStage, &c->matStage, &c->transDev, &c->outDev, &c->hitDev, &c->counterDev, &c->decayDev, &c->timelineDev, &c->wfArena})
         release(*b);
     for (auto& e : c->timingEvents) { (void)hipEventDestroy(e.first); (void)hipEventDestroy(e.second); }
@@ -370,6 +373,7 @@ int lrl_scene_upload(LrlContext* c, const LrlSceneView* s) {
     int rc = validateBVH(c, s, depth);
     if (rc) return rc;
     c->haveScene = false;
+    c->waterGX = c->waterGY = 0;      // a new scene: lrl_water_init again
 
     // nodes: the reference's 64-B own-box records -> 64-B inner records that hold both children's boxes
     uint32_t recCount = 1;
@@ -937,6 +941,49 @@ int lrl_timing_end(LrlContext* c, double* totalMs, uint32_t* launches) {
     *launches = c->timingUsed;
     c->timing = false;
     c->timingUsed = 0;
+    return LRL_OK;
+}
+
+int lrl_water_init(LrlContext* c, uint32_t gx, uint32_t gy, float k, float dt, const LrlWaterPoint* points, uint32_t firstTriangle,
+                   const LrlTriangle* triangles) {
+    if (!c || !points || !triangles) return LRL_ERR_INVALID_ARG;
+    if (!c->haveScene) return fail(c, LRL_ERR_NO_SCENE, "no scene uploaded");
+    if (gx < 2 || gy < 2 || uint64_t(gx) * gy > 16384u) return fail(c, LRL_ERR_LIMIT, "water grid must be 2 x 2 .. 16384 points");
+    const uint64_t count = 2ull * (gx - 1) * (gy - 1);
+    if (uint64_t(firstTriangle) + count > c->num.triangleNum) return fail(c, LRL_ERR_INVALID_ARG, "water triangles out of range");
+    HIP_TRY(c, hipSetDevice(c->device));
+    int rc = upload(c, c->waterPoints, points, size_t(gx) * gy * sizeof(LrlWaterPoint));
+    if (rc) return rc;
+    if ((rc = upload(c, c->waterTris, triangles, size_t(count) * sizeof(LrlTriangle)))) return rc;
+    std::vector<uint32_t> mat(count);
+    const size_t before = c->materialTable.size();
+    for (uint64_t i = 0; i < count; ++i) mat[i] = internMaterial(c, triangles[i].color);
+    if (c->materialTable.size() != before && (rc = upload(c, c->materials, c->materialTable.data(), c->materialTable.size() * sizeof(LrlColor)))) return rc;
+    if ((rc = upload(c, c->waterMat, mat.data(), mat.size() * 4))) return rc;
+    HIP_TRY(c, hipStreamSynchronize(c->stream));      // the host arrays are borrowed only for this call
+    c->waterGX = gx; c->waterGY = gy; c->waterFirst = firstTriangle; c->waterK = k; c->waterDt = dt;
+    return LRL_OK;
+}
+
+int lrl_water_step(LrlContext* c, uint32_t substeps) {
+    if (!c) return LRL_ERR_INVALID_ARG;
+    if (!c->waterGX) return fail(c, LRL_ERR_NO_SCENE, "lrl_water_init first");
+    HIP_TRY(c, hipSetDevice(c->device));
+    const uint32_t count = 2u * (c->waterGX - 1) * (c->waterGY - 1);
+    HIP_TRY(c, lrl_launch_water_run(static_cast<float4*>(c->waterPoints.p), c->waterGX, c->waterGY, c->waterK, c->waterDt, substeps,
+                                    static_cast<LrlTriangle*>(c->waterTris.p), c->stream));
+    HIP_TRY(c, lrl_launch_triangle_pre(static_cast<const LrlTriangle*>(c->waterTris.p), static_cast<const uint32_t*>(c->waterMat.p), c->waterFirst, count,
+                                       static_cast<float4*>(c->triHot.p), static_cast<LrlTriCold*>(c->triCold.p), c->stream));
+    return LRL_OK;
+}
+
+int lrl_water_read(LrlContext* c, LrlWaterPoint* points, LrlTriangle* triangles) {
+    if (!c) return LRL_ERR_INVALID_ARG;
+    if (!c->waterGX) return fail(c, LRL_ERR_NO_SCENE, "lrl_water_init first");
+    HIP_TRY(c, hipSetDevice(c->device));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    if (points) HIP_TRY(c, hipMemcpy(points, c->waterPoints.p, size_t(c->waterGX) * c->waterGY * sizeof(LrlWaterPoint), hipMemcpyDeviceToHost));
+    if (triangles) HIP_TRY(c, hipMemcpy(triangles, c->waterTris.p, size_t(2) * (c->waterGX - 1) * (c->waterGY - 1) * sizeof(LrlTriangle), hipMemcpyDeviceToHost));
     return LRL_OK;
 }
 

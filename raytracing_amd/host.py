@@ -62,8 +62,8 @@ class HostModel:
     def scene_bvh_default(self, resdir, load_cube=True):
         self._ck(self._L.lrlh_scene_bvh_default(self._h, os.fsencode(resdir), int(load_cube)))
 
-    def scene_mesh(self, stl_path, subdivisions=0):
-        self._ck(self._L.lrlh_scene_mesh(self._h, os.fsencode(stl_path), C.c_uint(subdivisions)))
+    def scene_mesh(self, stl_path, subdivisions=0, grid=1):
+        self._ck(self._L.lrlh_scene_mesh_grid(self._h, os.fsencode(stl_path), C.c_uint(subdivisions), C.c_uint(grid)))
 
     def scene_pool(self, resdir, load_textures=True):
         self._ck(self._L.lrlh_scene_pool(self._h, os.fsencode(resdir), int(load_textures)))

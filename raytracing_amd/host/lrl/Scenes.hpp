@@ -121,9 +121,31 @@ inline Camera bvhDefault(Model& m, std::string const& resdir, bool loadCube = tr
 }
 
 // C2: a single STL mesh on a ground disc.  The mesh is lifted so its lowest point rests on z = 0.
-inline Camera mesh(Model& m, STL const& in, unsigned subdivisions) {
+// grid > 1 (towards C5): grid x grid copies of the mesh side by side, vertices replicated (the format has no
+// instancing), on one disc, framed by the same camera recipe.
+inline Camera mesh(Model& m, STL const& in, unsigned subdivisions, unsigned grid = 1) {
     STL s = in;
     for (unsigned i = 0; i < subdivisions; ++i) s = s.subdivided();
+    if (grid > 1) {
+        float lo[2] = {FLT_MAX, FLT_MAX}, hi[2] = {-FLT_MAX, -FLT_MAX};
+        for (unsigned i = 0; i < s.triangles.length; ++i)
+            for (int v = 0; v < 3; ++v)
+                for (int k = 0; k < 2; ++k) {
+                    lo[k] = std::min(lo[k], s.triangles[i].vertices[v][k]);
+                    hi[k] = std::max(hi[k], s.triangles[i].vertices[v][k]);
+                }
+        const float pitch = 1.15f * std::max(hi[0] - lo[0], hi[1] - lo[1]);
+        const unsigned n0 = s.triangles.length;
+        for (unsigned gy = 0; gy < grid; ++gy)
+            for (unsigned gx = 0; gx < grid; ++gx) {
+                if (gx == 0 && gy == 0) continue;
+                for (unsigned i = 0; i < n0; ++i) {
+                    auto t = s.triangles[i];
+                    for (int v = 0; v < 3; ++v) { t.vertices[v][0] += pitch * gx; t.vertices[v][1] += pitch * gy; }
+                    s.triangles.pushBack(t);
+                }
+            }
+    }
     float mn[3] = {FLT_MAX, FLT_MAX, FLT_MAX}, mx[3] = {-FLT_MAX, -FLT_MAX, -FLT_MAX};
     for (unsigned i = 0; i < s.triangles.length; ++i)
         for (int v = 0; v < 3; ++v)

@@ -38,6 +38,9 @@ int lrlh_scene_bvh_default(Handle* h, const char* resdir, int loadCube) {
 int lrlh_scene_mesh(Handle* h, const char* stlPath, unsigned subdivisions) {
     return guarded([&] { h->cam = scenes::mesh(h->model, STL::readSTL(stlPath), subdivisions); });
 }
+int lrlh_scene_mesh_grid(Handle* h, const char* stlPath, unsigned subdivisions, unsigned grid) {
+    return guarded([&] { h->cam = scenes::mesh(h->model, STL::readSTL(stlPath), subdivisions, grid); });
+}
 int lrlh_scene_pool(Handle* h, const char* resdir, int loadTextures) {
     return guarded([&] { h->cam = scenes::pool(h->model, resdir, loadTextures != 0); h->poolWaterPending = true; });
 }

@@ -53,16 +53,17 @@ def bunny_triangles():
     return z["verts"][z["idx"]]          # [n, 3, 3] float32, winding already fixed against the STL normals
 
 
-def mesh_scene(subdivisions=2, builder="median", stl_path=None):
-    """the Stanford bunny (77 560 triangles) x `subdivisions` 1->4 midpoint levels."""
+def mesh_scene(subdivisions=2, builder="median", stl_path=None, grid=1):
+    """SURVEY §8d config C2: the Stanford bunny (77 560 triangles) x `subdivisions` 1->4 midpoint levels;
+    grid > 1: grid x grid replicated copies (towards C5)."""
     m = host.HostModel()
     if stl_path is None:
         with tempfile.TemporaryDirectory() as td:
             p = os.path.join(td, "bunny.stl")
             write_binary_stl(p, bunny_triangles())
-            m.scene_mesh(p, subdivisions)
+            m.scene_mesh(p, subdivisions, grid)
     else:
-        m.scene_mesh(stl_path, subdivisions)
+        m.scene_mesh(stl_path, subdivisions, grid)
     m.data_init(builder)
     return m
 
@@ -72,3 +73,28 @@ def pool(resdir=POOL_RESOURCES, load_textures=True, builder="reference"):
     m.scene_pool(resdir, load_textures)
     m.data_init(builder)
     return m
+
+
+POOL_GRID = (48, 48)            # groupSize * groupNum, Pool/Pool.cpp:484
+POOL_WATER = (0.0005, 0.05)     # k, dt (same line)
+
+
+def pool_water_points(model, gx=POOL_GRID[0], gy=POOL_GRID[1]):
+    """The water grid {z, v = 0, a = 0} of a Pool model, read back from the triangle corners the reference's
+    WaterPositionSync writes (Pool/shaders/WaterPositionSyncCompute0.cpp:53-74): the state WaterData starts from."""
+    from . import abi
+    t = model.arrays()["triangles"]
+    w = np.zeros(gx * gy, dtype=abi.WATER_POINT)
+    for y in range(gy):
+        for x in range(gx):
+            ti = x + y * 2 * (gx - 1)
+            if x != gx - 1 and y != gy - 1:
+                z = t["p1"][ti][2]
+            elif x != 0 and y != 0:
+                z = t["p1"][ti - gx][2]
+            elif x != 0:
+                z = t["p2"][ti - 1][2]
+            else:
+                z = t["p3"][ti - 2 * (gx - 1)][2]
+            w["z"][x + gx * y] = z
+    return w

@@ -19,7 +19,7 @@ EXPORTS = [
     "lrl_create", "lrl_destroy", "lrl_last_error", "lrl_version", "lrl_scene_upload", "lrl_scene_update_triangles",
     "lrl_scene_read_triangles_gpu", "lrl_scene_read_circles", "lrl_set_camera", "lrl_set_decay_origin", "lrl_compute_decay_origin",
     "lrl_render", "lrl_render_async", "lrl_sync", "lrl_get_counters", "lrl_last_kernel_ms", "lrl_scene_device_bytes",
-    "lrl_timing_begin", "lrl_timing_end",
+    "lrl_timing_begin", "lrl_timing_end", "lrl_water_init", "lrl_water_step", "lrl_water_read",
 ]
 
 
@@ -48,6 +48,9 @@ def lib():
         L.lrl_scene_device_bytes.argtypes = [C.c_void_p, C.POINTER(C.c_uint64)]
         L.lrl_timing_begin.argtypes = [C.c_void_p]
         L.lrl_timing_end.argtypes = [C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_uint32)]
+        L.lrl_water_init.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32, C.c_float, C.c_float, C.c_void_p, C.c_uint32, C.c_void_p]
+        L.lrl_water_step.argtypes = [C.c_void_p, C.c_uint32]
+        L.lrl_water_read.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
         _lib = L
     return _lib
 
@@ -108,6 +111,27 @@ class Tracer:
 
     def set_decay_origin(self, v):
         self._ck(self._L.lrl_set_decay_origin(self._ctx, (C.c_float * 4)(*[float(x) for x in v])))
+
+    # ---- Pool water simulation (lrl_water_*) ----
+    def water_init(self, gx, gy, k, dt, points, first_triangle, triangles):
+        w = np.ascontiguousarray(points, dtype=abi.WATER_POINT)
+        t = np.ascontiguousarray(triangles, dtype=abi.TRIANGLE)
+        if w.shape[0] != gx * gy or t.shape[0] != 2 * (gx - 1) * (gy - 1):
+            raise ValueError("water_init: gx * gy points and 2 (gx-1) (gy-1) triangles expected")
+        self._water = (gx, gy)
+        self._ck(self._L.lrl_water_init(self._ctx, C.c_uint32(gx), C.c_uint32(gy), C.c_float(k), C.c_float(dt), w.ctypes.data_as(C.c_void_p),
+                                        C.c_uint32(first_triangle), t.ctypes.data_as(C.c_void_p)))
+
+    def water_step(self, substeps):
+        self._ck(self._L.lrl_water_step(self._ctx, C.c_uint32(substeps)))
+
+    def water_read(self):
+        """-> (points, origin records of the water triangles)"""
+        gx, gy = self._water
+        w = np.zeros(gx * gy, dtype=abi.WATER_POINT)
+        t = np.zeros(2 * (gx - 1) * (gy - 1), dtype=abi.TRIANGLE)
+        self._ck(self._L.lrl_water_read(self._ctx, w.ctypes.data_as(C.c_void_p), t.ctypes.data_as(C.c_void_p)))
+        return w, t
 
     def compute_decay_origin(self, variant=abi.VARIANT_BVH):
         out = np.zeros(1, dtype=abi.DECAY_ORIGIN)

@@ -334,3 +334,60 @@ def test_pool_decay_origin_and_water_update(tracer, pool_model):
     fast1, _ = tracer.render(max_depth=8, variant=abi.VARIANT_POOL, mode=abi.MODE_FAST)
     assert image_stats(fast0, base)["rmse"] <= RMSE_FAST and image_stats(fast1, low)["rmse"] <= RMSE_FAST
     tracer.update_triangles(0, water)
+
+
+# ---- Pool water simulation on the device ----
+def test_water_simulation_bit_exact_on_device(tracer, pool_model):
+    """lrl_water_step against the llvmpipe fixture of the reference's three water shaders (z, v, a of every point, z of every
+    water-triangle corner: bit-identical after 1 and after 50 substeps, in one go or in pieces), against the oracle for a
+    longer run, and TrianglePre of the moved triangles against lrl_scene_update_triangles with the same triangles."""
+    g = np.load(os.path.join(GOLDEN, "pool_water_steps.npz"))
+    gx, gy, k, dt = int(g["gx"]), int(g["gy"]), float(g["k"]), float(g["dt"])
+    nw = 2 * (gx - 1) * (gy - 1)
+    view = pool_model.scene_view()
+    tris = pool_model.arrays()["triangles"]
+    w0 = scenes.pool_water_points(pool_model)
+
+    def state():
+        w, t = tracer.water_read()
+        return np.stack([w["z"], w["v"], w["a"]], axis=1), np.stack([t["p1"][:, 2], t["p2"][:, 2], t["p3"][:, 2]], axis=1), w, t
+
+    for pieces in ((1,), (50,), (20, 30)):
+        tracer.scene_upload(view)
+        tracer.water_init(gx, gy, k, dt, w0, 0, tris[:nw])
+        for n in pieces:
+            tracer.water_step(n)
+        zva, tz, _, _ = state()
+        n = sum(pieces)
+        assert np.array_equal(zva.view(np.uint32), g[f"zva_{n}"].view(np.uint32)), pieces
+        assert np.array_equal(tz.view(np.uint32), g[f"tri_z_{n}"].view(np.uint32)), pieces
+    # the reference's default frame: 200 substeps (Pool/Pool.cpp:484), against the oracle
+    tracer.water_step(150)
+    zva, tz, w, t = state()
+    ow = O.water_run(w0, gx, gy, k, dt, 200)
+    ot = O.water_sync(ow, gx, gy, tris)
+    assert np.array_equal(w["z"].view(np.uint32), ow["z"].view(np.uint32)) and np.array_equal(w["v"].view(np.uint32), ow["v"].view(np.uint32))
+    assert np.array_equal(t.view(np.uint8), ot[:nw].view(np.uint8))
+    # the tracer sees the moved water: same records as handing the triangles over from the host
+    dev = tracer.read_triangles_gpu(0, nw)
+    g2 = load_golden("pool_viewB_192")
+    tracer.set_camera(g2["trans"], g2["width"], g2["height"])
+    tracer.set_decay_origin((0, 0, 0, 1))
+    img_dev, hits_dev = tracer.render(max_depth=8, variant=abi.VARIANT_POOL)
+    tracer.scene_upload(view)
+    tracer.update_triangles(0, ot[:nw])
+    ref = tracer.read_triangles_gpu(0, nw)
+    assert np.array_equal(dev.view(np.uint8), ref.view(np.uint8))
+    img_ref, hits_ref = tracer.render(max_depth=8, variant=abi.VARIANT_POOL)
+    assert np.array_equal(img_dev.view(np.uint32), img_ref.view(np.uint32)) and np.array_equal(hits_dev, hits_ref)
+    oimg, ohits, _ = O.render(view_with(pool_model, ot), g2["trans"], g2["width"], g2["height"], max_depth=8, variant=abi.VARIANT_POOL, threads=8)
+    assert (ohits == hits_dev).all(axis=-1).mean() >= ID_BAR and image_stats(img_dev, oimg)["rmse"] <= RMSE_PARITY
+
+
+def view_with(model, triangles):
+    """The model's scene view with another triangle array (same count, same BVH: what the Pool does every frame)."""
+    v = model.scene_view()
+    keep = np.ascontiguousarray(triangles, dtype=abi.TRIANGLE)
+    view_with.keep = keep
+    v.trianglesOrigin = keep.ctypes.data
+    return v

@@ -92,3 +92,28 @@ def test_pool_underwater_view_and_decay_origin(pool_model):
     check(pool_model, "pool_underwater_128", decay=(0, 0, 0, 1))
     d = O.decay_origin(pool_model.scene_view(), g["trans"], variant=abi.VARIANT_POOL)
     np.testing.assert_allclose(d["decayOrigin"], [-1, -1, -1, 1.33], rtol=1e-6)
+
+
+# ---- Pool water simulation (next row f2): the oracle against the reference's compute shaders on llvmpipe ----
+def test_water_simulation_bit_exact(pool_model):
+    """n x (WaterAcceleration, WaterPosition) + WaterPositionSync: z, v, a of every grid point and the z of every water
+    triangle corner are bit-identical to llvmpipe's run of the reference shaders, after 1 and after 50 substeps."""
+    import os
+    from conftest import GOLDEN
+    g = np.load(os.path.join(GOLDEN, "pool_water_steps.npz"))
+    gx, gy, k, dt = int(g["gx"]), int(g["gy"]), float(g["k"]), float(g["dt"])
+    w0 = scenes.pool_water_points(pool_model)
+    np.testing.assert_array_equal(w0["z"].view(np.uint32), g["z0"].view(np.uint32))      # the scene's rest state is the fixture's input
+    tris = pool_model.arrays()["triangles"]
+    nw = 2 * (gx - 1) * (gy - 1)
+    for n in (1, 50):
+        w = O.water_run(w0, gx, gy, k, dt, n)
+        zva = np.stack([w["z"], w["v"], w["a"]], axis=1)
+        assert np.array_equal(zva.view(np.uint32), g[f"zva_{n}"].view(np.uint32)), n
+        t = O.water_sync(w, gx, gy, tris)
+        tz = np.stack([t["p1"][:nw, 2], t["p2"][:nw, 2], t["p3"][:nw, 2]], axis=1)
+        assert np.array_equal(tz.view(np.uint32), g[f"tri_z_{n}"].view(np.uint32)), n
+        assert np.array_equal(t[nw:].view(np.uint8), tris[nw:].view(np.uint8))
+    # split runs compose: 20 + 30 substeps = 50
+    w = O.water_run(O.water_run(w0, gx, gy, k, dt, 20), gx, gy, k, dt, 30)
+    assert np.array_equal(w["z"].view(np.uint32), g["zva_50"][:, 0].view(np.uint32))

@@ -107,6 +107,27 @@ def make_pool_goldens(ref):
     save("pool_underwater_128", O.run_reference(m, tC, 128, 128, shaders, decay_compute=True), tC, dict(width=128, height=128, depth=8, variant=1))
 
 
+def make_water_golden(ref):
+    """The reference's water simulation on llvmpipe (WaterAcceleration / WaterPosition / WaterPositionSync) from the Pool
+    scene's rest state: the grid after 1 and after 50 substeps, and the z of the three corners of every water triangle after
+    the sync that follows them (Pool/Pool.cpp:224-235, n = 50 instead of 200 to keep the fixture's run short)."""
+    shaders = os.path.join(ref, "Pool", "shaders")
+    m = scenes.pool()
+    tris = m.arrays()["triangles"]
+    gx, gy = scenes.POOL_GRID
+    k, dt = scenes.POOL_WATER
+    w0 = scenes.pool_water_points(m)
+    out = {"gx": gx, "gy": gy, "k": np.float32(k), "dt": np.float32(dt), "z0": w0["z"].copy()}
+    for n in (1, 50):
+        w, t = O.run_reference_water(w0, gx, gy, k, dt, n, tris, shaders)
+        nw = 2 * (gx - 1) * (gy - 1)
+        out[f"zva_{n}"] = np.stack([w["z"], w["v"], w["a"]], axis=1)
+        out[f"tri_z_{n}"] = np.stack([t["p1"][:nw, 2], t["p2"][:nw, 2], t["p3"][:nw, 2]], axis=1)
+        assert np.array_equal(t[nw:].view(np.uint8), tris[nw:].view(np.uint8))      # only the water triangles move
+    np.savez_compressed(os.path.join(GOLDEN, "pool_water_steps.npz"), **out)
+    print("pool_water_steps", {k: getattr(v, "shape", v) for k, v in out.items()})
+
+
 def save(name, ref, trans, meta):
     ids = ref["ids"]
     np.savez_compressed(os.path.join(GOLDEN, name + ".npz"), rgb=ref["img"][..., :3].copy(), hit_type=ids[..., 0].astype(np.uint8),
@@ -118,13 +139,17 @@ def save(name, ref, trans, meta):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--reference", default="/root/reference")
-    ap.add_argument("--only", default="", help="'pool': only the Pool assets and goldens")
+    ap.add_argument("--only", default="", help="'pool': only the Pool assets and goldens; 'water': only the water-simulation fixture")
     a = ap.parse_args()
     ref = a.reference
     os.makedirs(GOLDEN, exist_ok=True)
     if a.only == "pool":
         make_pool_assets(ref)
         make_pool_goldens(ref)
+        make_water_golden(ref)
+        return
+    if a.only == "water":
+        make_water_golden(ref)
         return
     make_assets(ref)
     bvh_shaders = os.path.join(ref, "BVH", "shaders")
@@ -167,6 +192,7 @@ def main():
 
     make_pool_assets(ref)
     make_pool_goldens(ref)
+    make_water_golden(ref)
 
 
 if __name__ == "__main__":
