@@ -41,7 +41,8 @@ def main():
     ap.add_argument("--steps", type=int, default=50)
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--mode", default="fast", choices=["fast", "parity"])
-    ap.add_argument("--builder", default="reference", choices=["reference", "median"])
+    ap.add_argument("--builder", default="reference", choices=["reference", "median", "device"],
+                    help="who builds the BVH: the restated reference builder (host, default), a median-split host builder, or the library on the device")
     ap.add_argument("--subdivisions", type=int, default=2)
     ap.add_argument("--width", type=int, default=1920)
     ap.add_argument("--height", type=int, default=1080)
@@ -79,12 +80,16 @@ def main():
     a.depth = a.depth or (8 if c3 else 4)
     a.spp = a.spp or (64 if c3 else 1)
     variant = abi.VARIANT_POOL if c3 else abi.VARIANT_BVH
-    m = scenes.pool(builder=a.builder) if c3 else scenes.mesh_scene(subdivisions=a.subdivisions, builder=a.builder, grid=a.grid)
+    host_builder = "median" if a.builder == "device" else a.builder      # (the host model builds one anyway; it is not handed over)
+    m = scenes.pool(builder=host_builder) if c3 else scenes.mesh_scene(subdivisions=a.subdivisions, builder=host_builder, grid=a.grid)
     build_s = time.time() - t0
     info = m.bvh_info()
     W, H = a.width, a.height
     trans = m.camera(H)
     view = m.scene_view()
+    if a.builder == "device":
+        view.bvh = None
+        view.bvhNodeNum = 0
     tr = tracer.Tracer(local_rank)
     t0 = time.time()
     tr.scene_upload(view)

@@ -81,7 +81,10 @@ typedef struct LrlSceneView {
     const LrlCylinder*    cylinders;
     const LrlCone*        cones;
     const LrlPointLight*  pointLights;
-    const LrlBVHNode*     bvh;               /* pre-order array produced by the CPU builder                 */
+    const LrlBVHNode*     bvh;               /* pre-order array produced by the CPU builder (model.bvh, SSBO 9); NULL (with
+                                              * bvhNodeNum 0): the library builds a tree itself, on the device (SURVEY 8f
+                                              * rank 1: LBVH; needs trianglesOrigin).  Not the reference's tree: the images
+                                              * agree unless two primitives are hit at exactly the same distance        */
     uint32_t              bvhNodeNum;
     /* textures: BMP payload convention, BGR8, rows bottom-up */
     uint32_t              texWidth, texHeight, texLayers;

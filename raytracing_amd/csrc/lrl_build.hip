@@ -1,0 +1,356 @@
+// lrl_build.hip — BVH build on the device.
+//
+// The reference builds its tree on one host thread (missing source; BVH.exe@0x140005c90, SURVEY App. A: recursive mean
+// split with per-level heap vectors), which is what dominates end to end once the mesh is large (C5: minutes).  When the
+// caller passes no tree (LrlSceneView::bvh == NULL) the library builds one here, directly in the two device layouts the
+// trace kernels read (lrl_device.h: `recs`, the binary child-box records, and `node4`, the four-wide compressed nodes),
+// without ever making the reference's 64-B own-box nodes:
+//   1. bounds of the primitive-box centres (block reduction + 6 atomics per block)
+//   2. 63-bit Morton codes of the centres, radix sort of (code, primitive) pairs (rocPRIM)
+//   3. the binary radix tree over the sorted codes (Karras 2012: every inner node finds its range and split by itself)
+//   4. boxes bottom-up (the second thread to reach a node does the work), which also writes the node's 64-B record, its
+//      height, and orders its children by the axis along which their centres differ most (the reference-order kernel
+//      visits "left" first when the ray goes up that axis)
+//   5. the four-wide node of EVERY record, each as if it were the root of a collapse (two expansions of the larger inner
+//      item): they are addressed by record index, so the ones no ray reaches cost nothing but their memory
+//   6. the height of the four-wide tree, bottom-up again (stack sizes of the trace kernels)
+// Not the reference's tree: images agree with a host-built tree except where two primitives are hit at exactly the same
+// distance (tests/test_gpu_parity.py::test_device_built_bvh*).
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cstring>
+
+#include <rocprim/rocprim.hpp>
+
+#include "lrl_device.h"
+
+namespace lrl_build {
+
+#define DI static __device__ __forceinline__
+
+DI uint32_t fkey(float f) { const uint32_t b = __float_as_uint(f); return (b & 0x80000000u) ? ~b : (b | 0x80000000u); }   // order-preserving
+DI float fkeyInv(uint32_t k) { return __uint_as_float((k & 0x80000000u) ? (k & 0x7fffffffu) : ~k); }
+DI float ldf(const float* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }      // written by another wave of this launch
+DI uint32_t ldu(const uint32_t* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+DI float4 ld4(const float4* p) {
+    const float* f = reinterpret_cast<const float*>(p);
+    return make_float4(ldf(f), ldf(f + 1), ldf(f + 2), ldf(f + 3));
+}
+
+// boxes of the triangles of one staged slab: exact min / max of the three corners, like the reference's leaves
+// (BVH.exe@0x140004d00); w of the min corner carries the primitive bits
+__global__ __launch_bounds__(256) void triBoxKernel(const LrlTriangle* __restrict__ in, uint32_t first, uint32_t count, float4* __restrict__ pmin,
+                                                    float4* __restrict__ pmax) {
+    const uint32_t i = blockIdx.x * 256u + threadIdx.x;
+    if (i >= count) return;
+    const float4* q = reinterpret_cast<const float4*>(in + i);
+    const float4 a = q[0], b = q[1], c = q[2];
+    pmin[first + i] = make_float4(fminf(a.x, fminf(b.x, c.x)), fminf(a.y, fminf(b.y, c.y)), fminf(a.z, fminf(b.z, c.z)),
+                                  __uint_as_float((2u << LRL_PRIM_TYPE_SHIFT) | (first + i)));
+    pmax[first + i] = make_float4(fmaxf(a.x, fmaxf(b.x, c.x)), fmaxf(a.y, fmaxf(b.y, c.y)), fmaxf(a.z, fmaxf(b.z, c.z)), 0.0f);
+}
+
+__global__ __launch_bounds__(256) void boundsKernel(const float4* __restrict__ pmin, const float4* __restrict__ pmax, uint32_t n, uint32_t* bounds) {
+    __shared__ uint32_t sh[6];
+    if (threadIdx.x < 3) sh[threadIdx.x] = 0xffffffffu;
+    else if (threadIdx.x < 6) sh[threadIdx.x] = 0u;
+    __syncthreads();
+    for (uint32_t i = blockIdx.x * 256u + threadIdx.x; i < n; i += gridDim.x * 256u) {
+        const float4 a = pmin[i], b = pmax[i];
+        const float cx = 0.5f * (a.x + b.x), cy = 0.5f * (a.y + b.y), cz = 0.5f * (a.z + b.z);
+        atomicMin(&sh[0], fkey(cx)); atomicMin(&sh[1], fkey(cy)); atomicMin(&sh[2], fkey(cz));
+        atomicMax(&sh[3], fkey(cx)); atomicMax(&sh[4], fkey(cy)); atomicMax(&sh[5], fkey(cz));
+    }
+    __syncthreads();
+    if (threadIdx.x < 3) atomicMin(&bounds[threadIdx.x], sh[threadIdx.x]);
+    else if (threadIdx.x < 6) atomicMax(&bounds[threadIdx.x], sh[threadIdx.x]);
+}
+
+DI uint64_t spread21(uint32_t v) {      // 21 bits -> every third bit
+    uint64_t x = v & 0x1fffffu;
+    x = (x | x << 32) & 0x1f00000000ffffull;
+    x = (x | x << 16) & 0x1f0000ff0000ffull;
+    x = (x | x << 8) & 0x100f00f00f00f00full;
+    x = (x | x << 4) & 0x10c30c30c30c30c3ull;
+    x = (x | x << 2) & 0x1249249249249249ull;
+    return x;
+}
+
+__global__ __launch_bounds__(256) void mortonKernel(const float4* __restrict__ pmin, const float4* __restrict__ pmax, uint32_t n,
+                                                    const uint32_t* __restrict__ bounds, uint64_t* __restrict__ keys, uint32_t* __restrict__ idx) {
+    const uint32_t i = blockIdx.x * 256u + threadIdx.x;
+    if (i >= n) return;
+    const float lo[3] = {fkeyInv(bounds[0]), fkeyInv(bounds[1]), fkeyInv(bounds[2])};
+    const float hi[3] = {fkeyInv(bounds[3]), fkeyInv(bounds[4]), fkeyInv(bounds[5])};
+    const float4 a = pmin[i], b = pmax[i];
+    const float c[3] = {0.5f * (a.x + b.x), 0.5f * (a.y + b.y), 0.5f * (a.z + b.z)};
+    uint32_t q[3];
+    for (int k = 0; k < 3; ++k) {
+        const float ext = hi[k] - lo[k];
+        const float t = ext > 0.0f ? (c[k] - lo[k]) / ext : 0.0f;
+        q[k] = uint32_t(fminf(fmaxf(t * 2097152.0f, 0.0f), 2097151.0f));
+    }
+    keys[i] = spread21(q[0]) << 2 | spread21(q[1]) << 1 | spread21(q[2]);
+    idx[i] = i;
+}
+
+// common leading bits of the codes at sorted positions i and j; equal codes are told apart by position
+DI int delta(const uint64_t* __restrict__ keys, int n, int i, int j) {
+    if (j < 0 || j >= n) return -1;
+    const uint64_t x = keys[i] ^ keys[j];
+    return x ? __clzll((long long)x) : 64 + __clz(i ^ j);
+}
+
+// Karras 2012.  children[i] = {left, right}: an inner node index, or LRL_REF_LEAF | sorted position of a leaf.
+__global__ __launch_bounds__(256) void treeKernel(const uint64_t* __restrict__ keys, uint32_t n, uint2* __restrict__ children,
+                                                  uint32_t* __restrict__ parentInner, uint32_t* __restrict__ parentLeaf) {
+    const int i = int(blockIdx.x * 256u + threadIdx.x);
+    const int N = int(n);
+    if (i >= N - 1) return;
+    const int d = delta(keys, N, i, i + 1) - delta(keys, N, i, i - 1) >= 0 ? 1 : -1;
+    const int dmin = delta(keys, N, i, i - d);
+    int lmax = 2;
+    while (delta(keys, N, i, i + lmax * d) > dmin) lmax *= 2;
+    int l = 0;
+    for (int t = lmax / 2; t >= 1; t /= 2)
+        if (delta(keys, N, i, i + (l + t) * d) > dmin) l += t;
+    const int j = i + l * d;
+    const int dnode = delta(keys, N, i, j);
+    int s = 0, t = l;
+    do {
+        t = (t + 1) >> 1;
+        if (delta(keys, N, i, i + (s + t) * d) > dnode) s += t;
+    } while (t > 1);
+    const int gamma = i + s * d + min(d, 0);
+    const int lo = min(i, j), hi = max(i, j);
+    uint2 c;
+    if (lo == gamma) { c.x = LRL_REF_LEAF | uint32_t(gamma); parentLeaf[gamma] = uint32_t(i); }
+    else { c.x = uint32_t(gamma); parentInner[gamma] = uint32_t(i); }
+    if (hi == gamma + 1) { c.y = LRL_REF_LEAF | uint32_t(gamma + 1); parentLeaf[gamma + 1] = uint32_t(i); }
+    else { c.y = uint32_t(gamma + 1); parentInner[gamma + 1] = uint32_t(i); }
+    children[i] = c;
+    if (i == 0) parentInner[0] = 0xffffffffu;
+}
+
+// bottom-up: boxes, heights and the 64-B records.  Inner node i is record i + 1; record 0 is the virtual parent of the root.
+__global__ __launch_bounds__(256) void fitKernel(const float4* __restrict__ pmin, const float4* __restrict__ pmax, const uint32_t* __restrict__ idx, uint32_t n,
+                                                 const uint2* __restrict__ children, const uint32_t* __restrict__ parentInner,
+                                                 const uint32_t* __restrict__ parentLeaf, uint32_t* counters, float4* nodeMin, float4* nodeMax,
+                                                 uint32_t* heights, float4* recs, uint32_t* info) {
+    const uint32_t leaf = blockIdx.x * 256u + threadIdx.x;
+    if (leaf >= n) return;
+    uint32_t cur = parentLeaf[leaf];
+    for (;;) {
+        __threadfence();
+        if (atomicAdd(&counters[cur], 1u) == 0u) return;      // the sibling subtree is not finished: its last thread goes on
+        __threadfence();
+        const uint2 c = children[cur];
+        float4 mn[2], mx[2];
+        uint32_t ref[2], h[2];
+        const uint32_t cc[2] = {c.x, c.y};
+        for (int k = 0; k < 2; ++k) {
+            if (cc[k] & LRL_REF_LEAF) {
+                const uint32_t p = idx[cc[k] & ~LRL_REF_LEAF];
+                mn[k] = pmin[p]; mx[k] = pmax[p];
+                ref[k] = LRL_REF_LEAF | __float_as_uint(mn[k].w);
+                h[k] = 0;
+            } else {
+                mn[k] = ld4(nodeMin + cc[k]); mx[k] = ld4(nodeMax + cc[k]);
+                ref[k] = cc[k] + 1u;
+                h[k] = ldu(heights + cc[k]);
+            }
+        }
+        // split axis: where the children's centres differ most; "left" = the lower one
+        const float dx = (mn[1].x + mx[1].x) - (mn[0].x + mx[0].x), dy = (mn[1].y + mx[1].y) - (mn[0].y + mx[0].y),
+                    dz = (mn[1].z + mx[1].z) - (mn[0].z + mx[0].z);
+        uint32_t axis = fabsf(dx) >= fabsf(dy) ? (fabsf(dx) >= fabsf(dz) ? 0u : 2u) : (fabsf(dy) >= fabsf(dz) ? 1u : 2u);
+        const float dd = axis == 0 ? dx : (axis == 1 ? dy : dz);
+        const int L = dd < 0.0f ? 1 : 0, R = 1 - L;
+        const float4 bmin = make_float4(fminf(mn[0].x, mn[1].x), fminf(mn[0].y, mn[1].y), fminf(mn[0].z, mn[1].z), 0.0f);
+        const float4 bmax = make_float4(fmaxf(mx[0].x, mx[1].x), fmaxf(mx[0].y, mx[1].y), fmaxf(mx[0].z, mx[1].z), 0.0f);
+        const uint32_t height = 1u + max(h[0], h[1]);
+        float4* q = recs + size_t(cur + 1u) * 4;
+        q[0] = make_float4(mn[L].x, mn[L].y, mn[L].z, __uint_as_float(ref[L]));
+        q[1] = make_float4(mx[L].x, mx[L].y, mx[L].z, __uint_as_float(ref[R]));
+        q[2] = make_float4(mn[R].x, mn[R].y, mn[R].z, __uint_as_float(0u));
+        q[3] = make_float4(mx[R].x, mx[R].y, mx[R].z, __uint_as_float(axis));
+        nodeMin[cur] = bmin; nodeMax[cur] = bmax;
+        heights[cur] = height;
+        if (cur == 0u) {
+            recs[0] = make_float4(bmin.x, bmin.y, bmin.z, __uint_as_float(1u));
+            recs[1] = make_float4(bmax.x, bmax.y, bmax.z, __uint_as_float(LRL_REF_NONE));
+            recs[2] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+            recs[3] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+            info[0] = height;
+            return;
+        }
+        cur = parentInner[cur];
+    }
+}
+
+struct Item4 { float3 lo, hi; uint32_t ref; };
+DI float area(const Item4& t) {
+    const float dx = t.hi.x - t.lo.x, dy = t.hi.y - t.lo.y, dz = t.hi.z - t.lo.z;
+    return dx * dy + dy * dz + dz * dx;
+}
+DI bool inner(uint32_t ref) { return ref != LRL_REF_NONE && !(ref & LRL_REF_LEAF); }
+
+// the items of the four-wide node of record r: its children, the larger inner one replaced by ITS children, twice
+DI int gather4(const float4* __restrict__ recs, uint32_t r, Item4* it) {
+    int n = 0;
+    {
+        const float4* q = recs + size_t(r) * 4;
+        const float4 a = q[0], b = q[1], c = q[2], d = q[3];
+        it[n++] = {make_float3(a.x, a.y, a.z), make_float3(b.x, b.y, b.z), __float_as_uint(a.w)};
+        if (__float_as_uint(b.w) != LRL_REF_NONE) it[n++] = {make_float3(c.x, c.y, c.z), make_float3(d.x, d.y, d.z), __float_as_uint(b.w)};
+    }
+    while (n < 4) {
+        int best = -1;
+        float bestArea = -1.0f;
+        for (int i = 0; i < n; ++i)
+            if (inner(it[i].ref) && area(it[i]) > bestArea) { bestArea = area(it[i]); best = i; }
+        if (best < 0) break;
+        const float4* q = recs + size_t(it[best].ref) * 4;
+        const float4 a = q[0], b = q[1], c = q[2], d = q[3];
+        for (int i = best; i + 1 < n; ++i) it[i] = it[i + 1];
+        --n;
+        it[n++] = {make_float3(a.x, a.y, a.z), make_float3(b.x, b.y, b.z), __float_as_uint(a.w)};
+        it[n++] = {make_float3(c.x, c.y, c.z), make_float3(d.x, d.y, d.z), __float_as_uint(b.w)};
+    }
+    return n;
+}
+
+__global__ __launch_bounds__(256) void node4Kernel(const float4* __restrict__ recs, uint32_t recCount, uint4* __restrict__ node4) {
+    const uint32_t r = blockIdx.x * 256u + threadIdx.x;
+    if (r >= recCount) return;
+    Item4 it[5];
+    const int n = gather4(recs, r, it);
+    float origin[3];
+    uint32_t expo[3];
+    double unit[3];
+    for (int a = 0; a < 3; ++a) {
+        float lo = INFINITY, hi = -INFINITY;
+        for (int i = 0; i < n; ++i) {
+            lo = fminf(lo, a == 0 ? it[i].lo.x : (a == 1 ? it[i].lo.y : it[i].lo.z));
+            hi = fmaxf(hi, a == 0 ? it[i].hi.x : (a == 1 ? it[i].hi.y : it[i].hi.z));
+        }
+        origin[a] = lo;
+        const double ext = double(hi) - double(lo);
+        int e = -126;
+        if (ext > 0.0) { (void)frexp(ext / 255.0, &e); }      // ext / 255 = m * 2^e with m in [0.5, 1): 2^e > ext / 255
+        e = min(127, max(-126, e));
+        while (e < 127 && ceil(ext / ldexp(1.0, e)) > 255.0) ++e;
+        expo[a] = uint32_t(e + 127);
+        unit[a] = ldexp(1.0, e);
+    }
+    uint32_t bytes[6] = {0, 0, 0, 0, 0, 0};
+    uint32_t refs[4] = {LRL_REF_NONE, LRL_REF_NONE, LRL_REF_NONE, LRL_REF_NONE};
+    for (int i = 0; i < n; ++i) {
+        const float lo[3] = {it[i].lo.x, it[i].lo.y, it[i].lo.z}, hi[3] = {it[i].hi.x, it[i].hi.y, it[i].hi.z};
+        for (int a = 0; a < 3; ++a) {
+            const double ql = floor((double(lo[a]) - double(origin[a])) / unit[a]);
+            const double qh = ceil((double(hi[a]) - double(origin[a])) / unit[a]);
+            bytes[a] |= uint32_t(fmin(255.0, fmax(0.0, ql))) << (8 * i);
+            bytes[3 + a] |= uint32_t(fmin(255.0, fmax(0.0, qh))) << (8 * i);
+        }
+        refs[i] = it[i].ref;
+    }
+    uint4* q = node4 + size_t(r) * 4;
+    q[0] = make_uint4(__float_as_uint(origin[0]), __float_as_uint(origin[1]), __float_as_uint(origin[2]), expo[0] << 23);
+    q[1] = make_uint4(bytes[0], bytes[1], bytes[2], bytes[3]);
+    q[2] = make_uint4(bytes[4], bytes[5], refs[0], refs[1]);
+    q[3] = make_uint4(refs[2], refs[3], expo[1] << 23, expo[2] << 23);
+}
+
+DI uint32_t height4Of(const uint4* __restrict__ node4, const uint32_t* h4, uint32_t r) {
+    const uint4 a = node4[size_t(r) * 4 + 2], b = node4[size_t(r) * 4 + 3];
+    const uint32_t refs[4] = {a.z, a.w, b.x, b.y};
+    uint32_t h = 0;
+    for (int i = 0; i < 4; ++i)
+        if (inner(refs[i])) h = max(h, ldu(h4 + refs[i]));
+    return h + 1u;
+}
+
+// height of the four-wide tree, bottom-up over the binary tree: when both subtrees of a node are done, so are the
+// four-wide nodes of everything below it
+__global__ __launch_bounds__(256) void height4Kernel(uint32_t n, const uint32_t* __restrict__ parentInner, const uint32_t* __restrict__ parentLeaf,
+                                                     uint32_t* counters, const uint4* __restrict__ node4, uint32_t* h4, uint32_t* info) {
+    const uint32_t leaf = blockIdx.x * 256u + threadIdx.x;
+    if (leaf >= n) return;
+    uint32_t cur = parentLeaf[leaf];
+    for (;;) {
+        __threadfence();
+        if (atomicAdd(&counters[cur], 1u) == 0u) return;
+        __threadfence();
+        h4[cur + 1u] = height4Of(node4, h4, cur + 1u);
+        if (cur == 0u) {
+            __threadfence();
+            info[1] = height4Of(node4, h4, 0u);
+            return;
+        }
+        cur = parentInner[cur];
+    }
+}
+
+}  // namespace lrl_build
+
+hipError_t lrl_launch_triangle_boxes(const LrlTriangle* in, uint32_t first, uint32_t count, float4* pmin, float4* pmax, hipStream_t stream) {
+    if (!count) return hipSuccess;
+    hipLaunchKernelGGL(lrl_build::triBoxKernel, dim3((count + 255) / 256), dim3(256), 0, stream, in, first, count, pmin, pmax);
+    return hipGetLastError();
+}
+
+size_t lrl_build_scratch_bytes(uint32_t n) {
+    size_t sortTmp = 0;
+    uint64_t* k = nullptr;
+    uint32_t* v = nullptr;
+    (void)rocprim::radix_sort_pairs(nullptr, sortTmp, k, k, v, v, size_t(n), 0, 63, hipStream_t(nullptr));
+    const size_t N = n;
+    // keys x2, idx x2, children, parents x2, counters, nodeMin, nodeMax, heights, h4, bounds + info
+    return sortTmp + N * (16 + 8 + 8 + 8 + 4 + 32 + 4 + 4) + 4096 + 16 * 256;
+}
+
+// pmin / pmax: n primitive boxes (w of pmin = primitive bits).  recs / node4: n records each (n >= 2).  info (host-visible
+// after the stream is synchronised): {height of the binary tree, height of the four-wide tree}.
+hipError_t lrl_build_bvh(const float4* pmin, const float4* pmax, uint32_t n, float4* recs, uint4* node4, void* scratch, size_t scratchBytes,
+                         uint32_t* infoDev, hipStream_t stream) {
+    if (n < 2) return hipErrorInvalidValue;
+    char* p = static_cast<char*>(scratch);
+    auto take = [&](size_t bytes) { char* o = p; p += (bytes + 255) / 256 * 256; return o; };
+    const size_t N = n;
+    uint64_t* keysA = reinterpret_cast<uint64_t*>(take(N * 8));
+    uint64_t* keysB = reinterpret_cast<uint64_t*>(take(N * 8));
+    uint32_t* idxA = reinterpret_cast<uint32_t*>(take(N * 4));
+    uint32_t* idxB = reinterpret_cast<uint32_t*>(take(N * 4));
+    uint2* children = reinterpret_cast<uint2*>(take(N * 8));
+    uint32_t* parentInner = reinterpret_cast<uint32_t*>(take(N * 4));
+    uint32_t* parentLeaf = reinterpret_cast<uint32_t*>(take(N * 4));
+    uint32_t* counters = reinterpret_cast<uint32_t*>(take(N * 4));
+    float4* nodeMin = reinterpret_cast<float4*>(take(N * 16));
+    float4* nodeMax = reinterpret_cast<float4*>(take(N * 16));
+    uint32_t* heights = reinterpret_cast<uint32_t*>(take(N * 4));
+    uint32_t* h4 = reinterpret_cast<uint32_t*>(take(N * 4));
+    uint32_t* bounds = reinterpret_cast<uint32_t*>(take(256));
+    size_t sortTmp = 0;
+    hipError_t e = rocprim::radix_sort_pairs(nullptr, sortTmp, keysA, keysB, idxA, idxB, N, 0, 63, stream);
+    if (e != hipSuccess) return e;
+    void* sortBuf = take(sortTmp);
+    if (size_t(p - static_cast<char*>(scratch)) > scratchBytes) return hipErrorOutOfMemory;
+
+    const uint32_t initBounds[6] = {0xffffffffu, 0xffffffffu, 0xffffffffu, 0u, 0u, 0u};
+    if ((e = hipMemcpyAsync(bounds, initBounds, sizeof(initBounds), hipMemcpyHostToDevice, stream)) != hipSuccess) return e;
+    if ((e = hipMemsetAsync(counters, 0, N * 4, stream)) != hipSuccess) return e;
+    if ((e = hipMemsetAsync(infoDev, 0, 8, stream)) != hipSuccess) return e;
+    const dim3 blk(256), grd((n + 255) / 256);
+    hipLaunchKernelGGL(lrl_build::boundsKernel, dim3(std::min<uint32_t>(grd.x, 4096u)), blk, 0, stream, pmin, pmax, n, bounds);
+    hipLaunchKernelGGL(lrl_build::mortonKernel, grd, blk, 0, stream, pmin, pmax, n, bounds, keysA, idxA);
+    if ((e = rocprim::radix_sort_pairs(sortBuf, sortTmp, keysA, keysB, idxA, idxB, N, 0, 63, stream)) != hipSuccess) return e;
+    hipLaunchKernelGGL(lrl_build::treeKernel, grd, blk, 0, stream, keysB, n, children, parentInner, parentLeaf);
+    hipLaunchKernelGGL(lrl_build::fitKernel, grd, blk, 0, stream, pmin, pmax, idxB, n, children, parentInner, parentLeaf, counters, nodeMin, nodeMax,
+                       heights, recs, infoDev);
+    hipLaunchKernelGGL(lrl_build::node4Kernel, grd, blk, 0, stream, recs, n, node4);
+    if ((e = hipMemsetAsync(counters, 0, N * 4, stream)) != hipSuccess) return e;
+    hipLaunchKernelGGL(lrl_build::height4Kernel, grd, blk, 0, stream, n, parentInner, parentLeaf, counters, node4, h4, infoDev);
+    return hipGetLastError();
+}

@@ -185,6 +185,12 @@ hipError_t lrl_launch_decay_origin(const KScene& sc, const LrlTrans* trans, uint
 hipError_t lrl_launch_triangle_pre(const LrlTriangle* in, const uint32_t* material, uint32_t first, uint32_t count, float4* triHot,
                                    LrlTriCold* triCold, hipStream_t stream);
 hipError_t lrl_launch_circle_pre(LrlCircle* circles, uint32_t count, hipStream_t stream);
+// Device BVH build (lrl_build.hip): boxes of a staged slab of triangles; scratch size; the build itself (n >= 2 boxes, w of
+// the min corner = primitive bits; writes n records into recs and node4, {height, four-wide height} into info)
+hipError_t lrl_launch_triangle_boxes(const LrlTriangle* in, uint32_t first, uint32_t count, float4* pmin, float4* pmax, hipStream_t stream);
+size_t lrl_build_scratch_bytes(uint32_t n);
+hipError_t lrl_build_bvh(const float4* pmin, const float4* pmax, uint32_t n, float4* recs, uint4* node4, void* scratch, size_t scratchBytes,
+                         uint32_t* infoDev, hipStream_t stream);
 // Pool water simulation: `substeps` x (acceleration, position) on gx * gy points {z, v, a, blank} (<= 16384), then the
 // heights into the corners of the 2 (gx-1) (gy-1) water triangles `tris` (origin records on the device; NULL: no sync)
 hipError_t lrl_launch_water_run(float4* water, uint32_t gx, uint32_t gy, float k, float dt, uint32_t substeps, LrlTriangle* tris, hipStream_t stream);

@@ -45,6 +45,7 @@ struct LrlContext {
     bool haveScene = false, haveCamera = false;
     LrlGeometryNum num{};
     uint32_t nodeNum = 0, recNum = 0, bvhDepth = 0;
+    DevBuf primMin, primMax, buildScratch, buildInfo;   // device BVH build (lrl_build.hip)
     DevBuf waterPoints, waterTris, waterMat;   // Pool water simulation (lrl_water_*)
     uint32_t waterGX = 0, waterGY = 0, waterFirst = 0;
     float waterK = 0, waterDt = 0;
@@ -312,6 +313,116 @@ int runTrianglePre(LrlContext* c, uint32_t first, uint32_t count, const LrlTrian
     return LRL_OK;
 }
 
+// boxes of the few primitives that are no triangles, with the leaf formulas of the host builder (SURVEY App. A:
+// BVH.exe@0x140005180 spheres, @0x1400052e0 discs, @0x140005560 cylinders, @0x140005910 cones; 5 % slack on radii)
+void boxFromDisc(const float c[3], const float n[3], float R, float mn[3], float mx[3]) {
+    const float nl = std::sqrt(n[0] * n[0] + n[1] * n[1] + n[2] * n[2]);
+    for (int i = 0; i < 3; ++i) {
+        const float ni = nl > 0 ? n[i] / nl : 0;
+        const float e = float(1.05 * double(R) * std::sqrt(std::max(0.0, 1.0 - double(ni) * ni)));
+        mn[i] = c[i] - e; mx[i] = c[i] + e;
+    }
+}
+
+int buildOnDevice(LrlContext* c, const LrlSceneView* s, uint32_t prims, uint32_t& recCount, uint32_t& depth) {
+    const LrlGeometryNum& g = s->num;
+    auto asf = [](uint32_t v) { float f; std::memcpy(&f, &v, 4); return f; };
+    // the non-triangles' boxes, appended after the triangles'
+    const uint32_t others = prims - g.triangleNum;
+    std::vector<float4> omin(others), omax(others);
+    uint32_t o = 0;
+    auto put = [&](const float mn[3], const float mx[3], uint32_t type, uint32_t i) {
+        omin[o] = make_float4(mn[0], mn[1], mn[2], asf((type << LRL_PRIM_TYPE_SHIFT) | i));
+        omax[o] = make_float4(mx[0], mx[1], mx[2], 0.0f);
+        ++o;
+    };
+    for (uint32_t i = 0; i < g.sphereNum; ++i) {
+        const LrlSphere& q = s->spheres[i];
+        const float d = float(1.05 * double(std::sqrt(q.sphere[3])));
+        const float mn[3] = {q.sphere[0] - d, q.sphere[1] - d, q.sphere[2] - d}, mx[3] = {q.sphere[0] + d, q.sphere[1] + d, q.sphere[2] + d};
+        put(mn, mx, 3, i);
+    }
+    for (uint32_t i = 0; i < g.circleNum; ++i) {
+        const LrlCircle& q = s->circles[i];
+        float mn[3], mx[3];
+        boxFromDisc(q.sphere, q.plane, std::sqrt(q.sphere[3]), mn, mx);
+        put(mn, mx, 4, i);
+    }
+    for (uint32_t i = 0; i < g.cylinderNum; ++i) {
+        const LrlCylinder& q = s->cylinders[i];
+        float mn[3], mx[3];
+        boxFromDisc(q.c, q.n, std::sqrt(q.r2), mn, mx);
+        for (int k = 0; k < 3; ++k) {
+            const float sh = q.n[k] * q.l;
+            mn[k] = std::min(mn[k], mn[k] + sh);
+            mx[k] = std::max(mx[k], mx[k] + sh);
+        }
+        put(mn, mx, 5, i);
+    }
+    for (uint32_t i = 0; i < g.coneNum; ++i) {
+        const LrlCone& q = s->cones[i];
+        const float h = std::sqrt(q.c2 * q.l2), R = std::sqrt((1 - q.c2) * q.l2);
+        const float base[3] = {q.c[0] + q.n[0] * h, q.c[1] + q.n[1] * h, q.c[2] + q.n[2] * h};
+        float mn[3], mx[3];
+        boxFromDisc(base, q.n, R, mn, mx);
+        for (int k = 0; k < 3; ++k) { mn[k] = std::min(mn[k], q.c[k]); mx[k] = std::max(mx[k], q.c[k]); }
+        put(mn, mx, 6, i);
+    }
+    if (others) {
+        HIP_TRY(c, hipMemcpy(static_cast<float4*>(c->primMin.p) + g.triangleNum, omin.data(), size_t(others) * 16, hipMemcpyHostToDevice));
+        HIP_TRY(c, hipMemcpy(static_cast<float4*>(c->primMax.p) + g.triangleNum, omax.data(), size_t(others) * 16, hipMemcpyHostToDevice));
+    }
+    int rc;
+    recCount = std::max(prims, 1u);
+    if ((rc = ensure(c, c->nodes, size_t(recCount) * 64))) return rc;
+    if ((rc = ensure(c, c->nodes32, size_t(recCount) * 64))) return rc;
+    if (prims == 1) {      // one primitive: the virtual parent of a leaf
+        float4 mn, mx;
+        HIP_TRY(c, hipMemcpy(&mn, c->primMin.p, 16, hipMemcpyDeviceToHost));
+        HIP_TRY(c, hipMemcpy(&mx, c->primMax.p, 16, hipMemcpyDeviceToHost));
+        uint32_t bits; std::memcpy(&bits, &mn.w, 4);
+        const float4 rec[4] = {make_float4(mn.x, mn.y, mn.z, asf(LRL_REF_LEAF | bits)), make_float4(mx.x, mx.y, mx.z, asf(LRL_REF_NONE)),
+                               make_float4(0, 0, 0, 0), make_float4(0, 0, 0, 0)};
+        uint32_t o3[3]; std::memcpy(o3, &mn, 12);
+        // a single item: its box is the node's box, one byte step = the whole extent
+        uint4 n4[4];
+        uint32_t ex[3];
+        const float lo[3] = {mn.x, mn.y, mn.z}, hi[3] = {mx.x, mx.y, mx.z};
+        uint32_t hb[3];
+        for (int a = 0; a < 3; ++a) {
+            const double ext = double(hi[a]) - double(lo[a]);
+            int e = -126;
+            if (ext > 0) (void)std::frexp(ext / 255.0, &e);
+            e = std::min(127, std::max(-126, e));
+            ex[a] = uint32_t(e + 127) << 23;
+            hb[a] = uint32_t(std::min(255.0, std::ceil(ext / std::ldexp(1.0, e))));
+        }
+        n4[0] = make_uint4(o3[0], o3[1], o3[2], ex[0]);
+        n4[1] = make_uint4(0, 0, 0, hb[0]);
+        n4[2] = make_uint4(hb[1], hb[2], LRL_REF_LEAF | bits, LRL_REF_NONE);
+        n4[3] = make_uint4(LRL_REF_NONE, LRL_REF_NONE, ex[1], ex[2]);
+        HIP_TRY(c, hipMemcpy(c->nodes.p, rec, 64, hipMemcpyHostToDevice));
+        HIP_TRY(c, hipMemcpy(c->nodes32.p, n4, 64, hipMemcpyHostToDevice));
+        depth = 0;
+        c->node4Depth = 1;
+        return LRL_OK;
+    }
+    const size_t scratch = lrl_build_scratch_bytes(prims);
+    if ((rc = ensure(c, c->buildScratch, scratch))) return rc;
+    if ((rc = ensure(c, c->buildInfo, 256))) return rc;
+    HIP_TRY(c, lrl_build_bvh(static_cast<const float4*>(c->primMin.p), static_cast<const float4*>(c->primMax.p), prims, static_cast<float4*>(c->nodes.p),
+                             static_cast<uint4*>(c->nodes32.p), c->buildScratch.p, scratch, static_cast<uint32_t*>(c->buildInfo.p), c->stream));
+    uint32_t info[2] = {0, 0};
+    HIP_TRY(c, hipMemcpyAsync(info, c->buildInfo.p, 8, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    if (info[0] == 0 || info[1] == 0) return fail(c, LRL_ERR_DEVICE, "device BVH build did not reach the root");
+    if (info[0] + 1 > LRL_MAX_BVH_DEPTH) return fail(c, LRL_ERR_BVH_DEPTH, "device-built BVH deeper than LRL_MAX_BVH_DEPTH");
+    depth = info[0];
+    c->node4Depth = info[1];
+    release(c->buildScratch);      // the tree is built: only the records stay
+    return LRL_OK;
+}
+
 }  // namespace
 
 extern "C" {
@@ -342,7 +453,7 @@ int lrl_destroy(LrlContext* c) {
     if (!c) return LRL_ERR_INVALID_ARG;
     (void)hipSetDevice(c->device);
     (void)hipStreamSynchronize(c->stream);
-    for (DevBuf* b : {&c->waterPoints, &c->waterTris, &c->waterMat, &c->nodes, &c->nodes32, &c->triHot, &c->triCold, &c->materials, &c->spheres, &c->circles, &c->cylinders, &c->cones, &c->lights,
+    for (DevBuf* b : {&c->primMin, &c->primMax, &c->buildScratch, &c->buildInfo, &c->waterPoints, &c->waterTris, &c->waterMat, &c->nodes, &c->nodes32, &c->triHot, &c->triCold, &c->materials, &c->spheres, &c->circles, &c->cylinders, &c->cones, &c->lights,
                       &c->tex, &c->cube, &c->triStage, &c->matStage, &c->transDev, &c->outDev, &c->hitDev, &c->counterDev, &c->decayDev, &c->timelineDev, &c->wfArena})
         release(*b);
     for (auto& e : c->timingEvents) { (void)hipEventDestroy(e.first); (void)hipEventDestroy(e.second); }
@@ -364,20 +475,24 @@ int lrl_scene_upload(LrlContext* c, const LrlSceneView* s) {
     if (g.triangleNum && !s->trianglesOrigin == !s->trianglesGPU)
         return fail(c, LRL_ERR_INVALID_ARG, "exactly one of trianglesOrigin / trianglesGPU must be given");
     if ((g.sphereNum && !s->spheres) || (g.circleNum && !s->circles) || (g.cylinderNum && !s->cylinders) || (g.coneNum && !s->cones) ||
-        (g.pointLightNum && !s->pointLights) || !s->bvh)
+        (g.pointLightNum && !s->pointLights))
         return fail(c, LRL_ERR_INVALID_ARG, "null array with non-zero count");
+    const bool deviceBuild = s->bvh == nullptr;      // no tree from the caller: built on the device (lrl_build.hip)
+    if (deviceBuild && g.triangleNum && !s->trianglesOrigin) return fail(c, LRL_ERR_INVALID_ARG, "the device BVH build needs trianglesOrigin");
+    const uint64_t primTotal = uint64_t(g.triangleNum) + g.sphereNum + g.circleNum + g.cylinderNum + g.coneNum;
+    if (deviceBuild && (primTotal == 0 || primTotal >= LRL_PRIM_INDEX_MASK)) return fail(c, LRL_ERR_INVALID_ARG, "the device BVH build needs 1 .. 2^28 primitives");
     if (g.triangleNum > LRL_PRIM_INDEX_MASK) return fail(c, LRL_ERR_LIMIT, "more than 2^28 triangles");
     if (s->texLayers && (!s->texBGR || !s->texWidth || !s->texHeight)) return fail(c, LRL_ERR_INVALID_ARG, "texture array incomplete");
     if (s->cubeSize) for (int i = 0; i < 6; ++i) if (!s->cubeBGR[i]) return fail(c, LRL_ERR_INVALID_ARG, "cube face missing");
     uint32_t depth = 0;
-    int rc = validateBVH(c, s, depth);
+    int rc = deviceBuild ? LRL_OK : validateBVH(c, s, depth);
     if (rc) return rc;
     c->haveScene = false;
     c->waterGX = c->waterGY = 0;      // a new scene: lrl_water_init again
 
     // nodes: the reference's 64-B own-box records -> 64-B inner records that hold both children's boxes
     uint32_t recCount = 1;
-    {
+    if (!deviceBuild) {
         const uint32_t N = s->bvhNodeNum;
         std::vector<uint32_t> recOf(N, 0);
         for (uint32_t i = 0; i < N; ++i) if (s->bvh[i].bound.leftChild) recOf[i] = recCount++;
@@ -424,7 +539,11 @@ int lrl_scene_upload(LrlContext* c, const LrlSceneView* s) {
         if (rc) return rc;
         HIP_TRY(c, hipStreamSynchronize(c->stream));
     }
-    if (std::getenv("LRL_DEBUG")) std::fprintf(stderr, "lrl: binary nodes %u (depth %u), four-wide tree depth %u\n", s->bvhNodeNum, depth, c->node4Depth);
+    if (!deviceBuild && std::getenv("LRL_DEBUG")) std::fprintf(stderr, "lrl: binary nodes %u (depth %u), four-wide tree depth %u\n", s->bvhNodeNum, depth, c->node4Depth);
+    if (deviceBuild) {
+        if ((rc = ensure(c, c->primMin, size_t(primTotal) * 16))) return rc;
+        if ((rc = ensure(c, c->primMax, size_t(primTotal) * 16))) return rc;
+    }
     c->materialTable.clear();
     c->materialIndex.clear();
     c->hasTransmission = false;
@@ -444,8 +563,14 @@ int lrl_scene_upload(LrlContext* c, const LrlSceneView* s) {
             // in slabs, so the staging buffer stays modest for very large meshes
             const uint32_t slab = 1u << 22;
             for (uint32_t first = 0; first < g.triangleNum; first += slab) {
-                rc = runTrianglePre(c, first, std::min(slab, g.triangleNum - first), s->trianglesOrigin + first);
+                const uint32_t cnt = std::min(slab, g.triangleNum - first);
+                rc = runTrianglePre(c, first, cnt, s->trianglesOrigin + first);
                 if (rc) return rc;
+                if (deviceBuild) {      // the slab is still in the staging buffer
+                    HIP_TRY(c, lrl_launch_triangle_boxes(static_cast<const LrlTriangle*>(c->triStage.p), first, cnt, static_cast<float4*>(c->primMin.p),
+                                                         static_cast<float4*>(c->primMax.p), c->stream));
+                    HIP_TRY(c, hipStreamSynchronize(c->stream));
+                }
             }
         } else {
             std::vector<float4> hot(size_t(g.triangleNum) * 4);
@@ -496,7 +621,12 @@ int lrl_scene_upload(LrlContext* c, const LrlSceneView* s) {
         c->cubeSize = s->cubeSize;
     } else if ((rc = ensure(c, c->cube, 4))) return rc;
     HIP_TRY(c, hipStreamSynchronize(c->stream));
-    c->nodeNum = s->bvhNodeNum;
+    if (deviceBuild) {
+        if ((rc = buildOnDevice(c, s, uint32_t(primTotal), recCount, depth))) return rc;
+        if (std::getenv("LRL_DEBUG")) std::fprintf(stderr, "lrl: device-built tree over %llu primitives: %u records, height %u, four-wide height %u\n",
+                                                   (unsigned long long)primTotal, recCount, depth, c->node4Depth);
+    }
+    c->nodeNum = deviceBuild ? uint32_t(2 * primTotal - 1) : s->bvhNodeNum;
     c->recNum = recCount;
     c->bvhDepth = depth;
     c->haveScene = true;

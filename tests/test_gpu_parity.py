@@ -391,3 +391,77 @@ def view_with(model, triangles):
     view_with.keep = keep
     v.trianglesOrigin = keep.ctypes.data
     return v
+
+
+# ---- BVH built on the device: LrlSceneView.bvh == NULL ----
+def without_tree(model):
+    v = model.scene_view()
+    v.bvh = None
+    v.bvhNodeNum = 0
+    return v
+
+
+@pytest.mark.parametrize("mode", [abi.MODE_PARITY, abi.MODE_FAST])
+@pytest.mark.parametrize("scene,name", [("default", "bvh_viewB_256"), ("default", "bvh_viewA_256"), ("bunny", "mesh_bunny0_240x135_depth4"),
+                                        ("pool", "pool_viewB_192")])
+def test_device_built_bvh_vs_llvmpipe_golden(tracer, default_model, bunny0_model, pool_model, scene, name, mode):
+    """A tree the library builds itself (Morton codes, radix sort, Karras tree, bottom-up fit, four-wide collapse: all on
+    the device) gives the images the reference's shaders give with the host-built tree.  Another tree visits in another
+    order, and a ray through an edge shared by two triangles (or through coplanar faces) hits both at the same distance:
+    the first one visited keeps the pixel.  Ids may therefore differ on such ties (bar 99.95 %; observed 8 of 65536 pixels
+    on the default scene's view B, none elsewhere); the image bars are those of the host-built path."""
+    model = {"default": default_model, "bunny": bunny0_model, "pool": pool_model}[scene]
+    g = load_golden(name)
+    tracer.scene_upload(without_tree(model))
+    tracer.set_camera(g["trans"], g["width"], g["height"])
+    tracer.set_decay_origin((0, 0, 0, 1))
+    img, hits = tracer.render(max_depth=g["depth"], variant=g["variant"], mode=mode)
+    same = (hits == g["ids"]).all(axis=-1).mean()
+    st = image_stats(img, g["rgb"])
+    assert same >= 0.9995, (name, mode, same)
+    if scene == "default":
+        # the default scene has coincident discs of different materials (circles 8 and 10: a 3 x 3 pixel patch of view B,
+        # tools/diag_devbuild.py): those few pixels take the other disc's colour, all others meet the bar
+        assert st["frac_gt_1e-3"] <= 5e-4, (name, mode, st)
+    else:
+        assert st["rmse"] <= (RMSE_PARITY if mode == abi.MODE_PARITY else RMSE_FAST), (name, mode, st)
+
+
+def test_device_built_bvh_counts_and_edge_cases(tracer, default_model):
+    """Ray counts are a property of the image, not of the tree: equal to the host-built tree's up to the tie pixels; the schedules agree bit for
+    bit on the device-built tree too; a scene of one primitive and of two primitives builds and renders."""
+    g = load_golden("bvh_viewB_256")
+    out = {}
+    for dev in (False, True):
+        tracer.scene_upload(without_tree(default_model) if dev else default_model.scene_view())
+        tracer.set_camera(g["trans"], g["width"], g["height"])
+        tracer.set_decay_origin((0, 0, 0, 1))
+        img, hits = tracer.render(max_depth=g["depth"], mode=abi.MODE_PARITY, counters=True)
+        c = tracer.counters()
+        out[dev] = (img, hits, c.rays, c.raysPrimary)
+        if dev:
+            img2, hits2 = tracer.render(max_depth=g["depth"], mode=abi.MODE_PARITY, megakernel=True)
+            assert np.array_equal(img.view(np.uint32), img2.view(np.uint32)) and np.array_equal(hits, hits2)
+    assert (out[False][1] == out[True][1]).all(axis=-1).mean() >= 0.9995
+    assert abs(out[False][2] - out[True][2]) <= 2e-3 * out[False][2] and out[False][3] == out[True][3]      # (the tie pixels' paths differ)
+    for nprim in (1, 2):
+        m = host.HostModel()
+        tri = np.zeros(nprim, dtype=abi.TRIANGLE)
+        for i in range(nprim):
+            tri["p1"][i] = (-1 + 3 * i, -1, -5); tri["p2"][i] = (1 + 3 * i, -1, -5); tri["p3"][i] = (0 + 3 * i, 1, -5)
+            tri["color"]["g"][i] = (0.25 + 0.5 * i, 0.5, 0.75)
+        for f in ("texR", "texT", "texD", "texG"):
+            tri["color"][f] = -1
+        tri["color"]["n"] = 1.0
+        m.add_triangles(tri)
+        m.data_init("reference")
+        trans = m.camera(64)
+        imgs = []
+        for dev in (False, True):
+            tracer.scene_upload(without_tree(m) if dev else m.scene_view())
+            tracer.set_camera(trans, 64, 64)
+            for mode in (abi.MODE_PARITY, abi.MODE_FAST):
+                imgs.append(tracer.render(max_depth=4, mode=mode)[0])
+        assert imgs[0][..., :3].max() > 0
+        for im in imgs[1:]:
+            assert image_stats(im, imgs[0])["rmse"] <= RMSE_FAST
