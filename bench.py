@@ -80,10 +80,12 @@ def main():
     a.depth = a.depth or (8 if c3 else 4)
     a.spp = a.spp or (64 if c3 else 1)
     variant = abi.VARIANT_POOL if c3 else abi.VARIANT_BVH
-    host_builder = "median" if a.builder == "device" else a.builder      # (the host model builds one anyway; it is not handed over)
-    m = scenes.pool(builder=host_builder) if c3 else scenes.mesh_scene(subdivisions=a.subdivisions, builder=host_builder, grid=a.grid)
+    if c3:
+        m = scenes.pool(builder="reference" if a.builder == "device" else a.builder)      # (the Pool model always builds its tree; not handed over)
+    else:
+        m = scenes.mesh_scene(subdivisions=a.subdivisions, builder="none" if a.builder == "device" else a.builder, grid=a.grid)
     build_s = time.time() - t0
-    info = m.bvh_info()
+    info = m.bvh_info() if a.builder != "device" or c3 else {"nodes": 0, "max_depth": 0}
     W, H = a.width, a.height
     trans = m.camera(H)
     view = m.scene_view()
@@ -174,7 +176,7 @@ def main():
                                    f"{W}x{H}, {a.spp} spp per GPU, RayTraceDepth {a.depth}",
                        "bvh_builder": a.builder, "bvh_nodes": info["nodes"], "bvh_depth": info["max_depth"], "arithmetic": a.mode,
                        "parallelism": f"replicated scene, {a.spp} sample indices per GPU, RCCL all-reduce of the image" if world > 1 else "1 GPU",
-                       "rays_per_frame": int(rays), "host_bvh_build_s": round(build_s, 2), "scene_upload_s": round(upload_s, 2),
+                       "rays_per_frame": int(rays), "host_scene_build_s": round(build_s, 2), "scene_upload_s": round(upload_s, 2),
                        "device_scene_bytes": dbytes},
             "roofline": {"bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBPS, 5), "traffic": traffic, "kernel_ms": round(kernel_ms, 4),

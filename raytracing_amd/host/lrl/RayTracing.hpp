@@ -315,7 +315,12 @@ struct Model {
 
     // model.dataInit() (BVH/BVH.cpp:722): counts + full CPU BVH rebuild.  The upload half is
     // lrl_scene_upload(ctx, &model.sceneView()).
-    void dataInit() {
+    // counts only, no tree: for callers that let the tracer library build the BVH on the device (LrlSceneView::bvh = NULL)
+    void dataInitWithoutTree() {
+        dataInit(false);
+        bvh.data.nodes.clear();
+    }
+    void dataInit(bool buildTree = true) {
         LrlGeometryNum& g = geometryNum.data.num;
         g.planeNum = planes.data.planes.length;
         g.triangleNum = triangles.trianglesOrigin.trianglesOrigin.length;
@@ -324,7 +329,7 @@ struct Model {
         g.cylinderNum = cylinders.data.cylinders.length;
         g.coneNum = cones.data.cones.length;
         g.pointLightNum = pointLights.data.pointLights.length;
-        buildBVH();
+        if (buildTree) buildBVH();
         triangles.GPUUpToDate = false;
         circles.GPUUpToDate = false;
         moved = true;

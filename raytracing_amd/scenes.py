@@ -64,7 +64,7 @@ def mesh_scene(subdivisions=2, builder="median", stl_path=None, grid=1):
             m.scene_mesh(p, subdivisions, grid)
     else:
         m.scene_mesh(stl_path, subdivisions, grid)
-    m.data_init(builder)
+    m.data_init(builder)             # "none": counts only, no host tree (LrlSceneView.bvh = NULL: the library builds one on the device)
     return m
 
 
