@@ -183,7 +183,7 @@ def main():
                          "kernel": "trace kernels of one frame (wfTraceLeanKernel + wfTraceSwarmKernel)" if a.mode == "fast" else "trace kernels of one frame (wfTraceKernel)",
                          "launches_per_frame": trace_launches // TRACE_FRAMES, "frame_ms": round(frame_ms, 4),
                          "frame_frac": round(alg_bytes / (frame_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS, 5),
-                         "algorithmic_bytes_per_launch": int(alg_bytes),
+                         "algorithmic_bytes_per_frame": int(alg_bytes),
                          "counts": {"node_visits": int(cn.nodeVisits), "tri_tests": int(cn.triTests), "sphere_tests": int(cn.sphereTests),
                                     "other_tests": int(cn.otherTests), "rays": int(rays)}},
         }
