@@ -67,6 +67,7 @@ struct LrlContext {
     uint32_t* contHost = nullptr;
     hipEvent_t evCont = nullptr;
     uint32_t contIters = 0;             // words of contHost in flight / ready
+    std::vector<LrlTrans> transUploaded;   // what transDev holds (per-sample cameras of the last render)
     std::vector<uint32_t> handoverThr;  // per iteration index; empty until first use
     std::vector<uint32_t> swarmGrid;    // waves launched for the handed-over rays of that iteration (a grid-stride kernel)
     hipEvent_t evIter[2] = {nullptr, nullptr};
@@ -695,6 +696,7 @@ int lrl_compute_decay_origin(LrlContext* c, uint32_t variant, LrlDecayOrigin* ou
     if (!c->haveScene || !c->haveCamera) return fail(c, LRL_ERR_NO_SCENE, "scene and camera must be set first");
     HIP_TRY(c, hipSetDevice(c->device));
     int rc = upload(c, c->transDev, &c->trans, sizeof(LrlTrans));
+    c->transUploaded.clear();      // transDev no longer holds a render's per-sample cameras
     if (rc) return rc;
     if ((rc = ensure(c, c->decayDev, sizeof(LrlDecayOrigin)))) return rc;
     KScene k;
@@ -904,11 +906,18 @@ static int renderImpl(LrlContext* c, const LrlRenderParams* p, float* rgbaDev, u
                 tr[s].trans[i][2] = c->trans.trans[i][2] + (c->trans.trans[i][0] * (2.0f * dx / c->trans.z0) + c->trans.trans[i][1] * (2.0f * dy / c->trans.z0));
         }
     }
-    HIP_TRY(c, hipStreamSynchronize(c->stream));
-    int rc = ensure(c, c->transDev, tr.size() * sizeof(LrlTrans));
-    if (rc) return rc;
-    HIP_TRY(c, hipMemcpyAsync(c->transDev.p, tr.data(), tr.size() * sizeof(LrlTrans), hipMemcpyHostToDevice, stream));
-    HIP_TRY(c, hipStreamSynchronize(stream));   // `tr` is a local
+    int rc = LRL_OK;
+    // the per-sample cameras go to the device only when they changed: an unchanged camera costs no copy and no host wait,
+    // so consecutive frames queue back to back
+    if (c->transUploaded.size() != tr.size() || std::memcmp(c->transUploaded.data(), tr.data(), tr.size() * sizeof(LrlTrans)) != 0) {
+        HIP_TRY(c, hipStreamSynchronize(c->stream));      // renders in flight still read the old ones
+        if (stream != c->stream) HIP_TRY(c, hipStreamSynchronize(stream));
+        c->transUploaded.clear();
+        if ((rc = ensure(c, c->transDev, tr.size() * sizeof(LrlTrans)))) return rc;
+        HIP_TRY(c, hipMemcpyAsync(c->transDev.p, tr.data(), tr.size() * sizeof(LrlTrans), hipMemcpyHostToDevice, stream));
+        HIP_TRY(c, hipStreamSynchronize(stream));   // `tr` is a local
+        c->transUploaded = tr;
+    }
     unsigned long long* ctr = nullptr;
     if (p->flags & LRL_FLAG_COUNTERS) {
         if ((rc = ensure(c, c->counterDev, LRL_CTR_COUNT * 8))) return rc;
