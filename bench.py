@@ -14,9 +14,10 @@ HIP events around every trace launch in a separate short pass (the event records
 pass is not the one `value` comes from).  frame_ms is the device time of the whole pipeline.
 
 N > 1 (torchrun, one rank per GPU): the scene is replicated; every rank renders the whole frame for
-ONE sample of an N-sample jitter table (sample-index sharding, so per-GPU work is fixed: weak
+its own sample(s) of an N x spp jitter table (sample-index sharding, so per-GPU work is fixed: weak
 scaling) and the partial means are summed with one RCCL all-reduce per step, inside the timed
-region.  value = rays of all ranks / max-over-ranks time.
+region; the all-reduce of a frame overlaps the rendering of the next one (two image buffers).
+value = rays of all ranks / max-over-ranks time.
 
   python bench.py [--gpus N] [--steps K] [--warmup W] [--mode fast|parity] [--builder reference|median] [--workload c2|c3]
 
@@ -68,11 +69,19 @@ def main():
         raise SystemExit(f"--gpus {a.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {a.gpus}")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the HIP path has no CPU fallback")
+    # rehearsal on a one-GPU box only (never the measured configuration): LRL_BENCH_REHEARSE=1 puts every rank on GPU 0 and
+    # combines over gloo, to run the N > 1 code path end to end where RCCL cannot (it refuses two ranks on one device)
+    rehearse = world > 1 and os.environ.get("LRL_BENCH_REHEARSE") == "1"
+    if rehearse:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group(backend="nccl", device_id=dev)
+        if rehearse:
+            dist.init_process_group(backend="gloo")
+        else:
+            dist.init_process_group(backend="nccl", device_id=dev)
 
     # ---- scene: built on the host by the restated reference library, uploaded once ----
     t0 = time.time()
@@ -110,17 +119,37 @@ def main():
     rays, alg_bytes = cn.rays, cn.algorithmic_bytes()
 
     out = torch.empty((H, W, 4), dtype=torch.float32, device=dev)
+    # N > 1: two image buffers, so that the all-reduce of frame i (RCCL's own stream) runs while frame i + 1 renders.  The
+    # render stream waits for the collective that last used a buffer before rendering into it again (stream-level waits
+    # only, no host wait inside the loop); every step still does one render and one all-reduce.
+    outs = [out, torch.empty_like(out)] if world > 1 else [out]
+    works = [None, None]
+    render_stream = torch.cuda.Stream(device=dev) if world > 1 else None
+    counter = [0]
 
     def step():
-        tr.render_device(out.data_ptr(), max_depth=a.depth, variant=variant, mode=mode, jitter=jitter, samples=samples)
-        if world > 1:
-            tr.sync()                       # the library renders on its own stream; the collective runs on torch's
-            dist.all_reduce(out, op=dist.ReduceOp.SUM)
+        if world == 1:
+            tr.render_device(out.data_ptr(), max_depth=a.depth, variant=variant, mode=mode, jitter=jitter, samples=samples)
+            return
+        b = counter[0] & 1
+        counter[0] += 1
+        with torch.cuda.stream(render_stream):
+            if works[b] is not None:
+                works[b].wait()
+            tr.render_device(outs[b].data_ptr(), stream=render_stream.cuda_stream, max_depth=a.depth, variant=variant, mode=mode,
+                             jitter=jitter, samples=samples)
+            works[b] = dist.all_reduce(outs[b], op=dist.ReduceOp.SUM, async_op=True)
+
+    def drain():
+        for w in works:
+            if w is not None:
+                w.wait()
+        tr.sync()
+        torch.cuda.synchronize()
 
     for _ in range(a.warmup):
         step()
-    tr.sync()
-    torch.cuda.synchronize()
+    drain()
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
@@ -128,8 +157,7 @@ def main():
     t0 = time.perf_counter()
     for _ in range(a.steps):
         step()
-    tr.sync()
-    torch.cuda.synchronize()
+    drain()
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
