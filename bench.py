@@ -74,6 +74,8 @@ def main():
     rehearse = world > 1 and os.environ.get("LRL_BENCH_REHEARSE") == "1"
     if rehearse:
         local_rank = 0
+        import faulthandler
+        faulthandler.dump_traceback_later(60, exit=True)      # a hang names its line
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     if world > 1:
@@ -134,16 +136,21 @@ def main():
         b = counter[0] & 1
         counter[0] += 1
         with torch.cuda.stream(render_stream):
-            if works[b] is not None:
-                works[b].wait()
+            # frame i renders (into the buffer whose all-reduce, of frame i - 2, was waited for in the last step) while the
+            # all-reduce of frame i - 1 runs; then that one is waited for (RCCL: a wait of the render stream, not of the
+            # host) and the all-reduce of frame i is queued behind its render: never more than one collective in flight
             tr.render_device(outs[b].data_ptr(), stream=render_stream.cuda_stream, max_depth=a.depth, variant=variant, mode=mode,
                              jitter=jitter, samples=samples)
+            if works[1 - b] is not None:
+                works[1 - b].wait()
+                works[1 - b] = None
             works[b] = dist.all_reduce(outs[b], op=dist.ReduceOp.SUM, async_op=True)
 
     def drain():
-        for w in works:
-            if w is not None:
-                w.wait()
+        for i in (0, 1):
+            if works[i] is not None:
+                works[i].wait()
+                works[i] = None
         tr.sync()
         torch.cuda.synchronize()
 
