@@ -152,6 +152,12 @@ int lrl_last_kernel_ms(LrlContext* ctx, float* ms);
 #define LRL_MAX_TIMED_LAUNCHES 4096u
 int lrl_timing_begin(LrlContext* ctx);
 int lrl_timing_end(LrlContext* ctx, double* total_ms, uint32_t* launches);
+/* Rebuild the tree the library built itself (scene uploaded with LrlSceneView.bvh == NULL) from the CURRENT triangles, after
+ * lrl_scene_update_triangles or lrl_water_step moved some: the reference has no counterpart (its Pool keeps tall static boxes
+ * around the moving water, /root/reference/Pool/Pool.cpp:250-263; SURVEY 8f rank 1 asks for a refit instead; a rebuild of a
+ * small scene costs the same and gives tight boxes).  Error when the caller supplied the tree. */
+int lrl_scene_rebuild_bvh(LrlContext* ctx);
+
 /* ---- Pool water simulation (replaces WaterSimulation of /root/reference/Pool/Pool.cpp:46-235 and the
  * shaders Pool/shaders/WaterAccelerationCompute0.cpp, WaterPositionCompute0.cpp, WaterPositionSyncCompute0.cpp) ----
  * The water is a gx x gy grid of points (Pool/Pool.cpp:84-90, buffer binding 10); its 2 (gx-1) (gy-1) triangles are

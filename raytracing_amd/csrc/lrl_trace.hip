@@ -43,6 +43,8 @@ struct LrlContext {
 
     // scene
     bool haveScene = false, haveCamera = false;
+    bool deviceBuilt = false;      // the tree was built by lrl_build.hip: primMin / primMax hold the primitives' boxes
+    uint32_t primTotal = 0;
     LrlGeometryNum num{};
     uint32_t nodeNum = 0, recNum = 0, bvhDepth = 0;
     DevBuf primMin, primMax, buildScratch, buildInfo;   // device BVH build (lrl_build.hip)
@@ -310,6 +312,9 @@ int runTrianglePre(LrlContext* c, uint32_t first, uint32_t count, const LrlTrian
     if (rc) return rc;
     HIP_TRY(c, lrl_launch_triangle_pre(static_cast<const LrlTriangle*>(c->triStage.p), static_cast<const uint32_t*>(c->matStage.p), first,
                                        count, static_cast<float4*>(c->triHot.p), static_cast<LrlTriCold*>(c->triCold.p), c->stream));
+    if (c->deviceBuilt && c->haveScene)      // keep the boxes current for lrl_scene_rebuild_bvh
+        HIP_TRY(c, lrl_launch_triangle_boxes(static_cast<const LrlTriangle*>(c->triStage.p), first, count, static_cast<float4*>(c->primMin.p),
+                                             static_cast<float4*>(c->primMax.p), c->stream));
     HIP_TRY(c, hipStreamSynchronize(c->stream));   // `mat` and the caller's array are borrowed only for this call
     return LRL_OK;
 }
@@ -324,6 +329,8 @@ void boxFromDisc(const float c[3], const float n[3], float R, float mn[3], float
         mn[i] = c[i] - e; mx[i] = c[i] + e;
     }
 }
+
+int runDeviceBuild(LrlContext* c, uint32_t prims, uint32_t& recCount, uint32_t& depth);
 
 int buildOnDevice(LrlContext* c, const LrlSceneView* s, uint32_t prims, uint32_t& recCount, uint32_t& depth) {
     const LrlGeometryNum& g = s->num;
@@ -373,6 +380,12 @@ int buildOnDevice(LrlContext* c, const LrlSceneView* s, uint32_t prims, uint32_t
         HIP_TRY(c, hipMemcpy(static_cast<float4*>(c->primMin.p) + g.triangleNum, omin.data(), size_t(others) * 16, hipMemcpyHostToDevice));
         HIP_TRY(c, hipMemcpy(static_cast<float4*>(c->primMax.p) + g.triangleNum, omax.data(), size_t(others) * 16, hipMemcpyHostToDevice));
     }
+    return runDeviceBuild(c, prims, recCount, depth);
+}
+
+// the build proper, from the boxes in primMin / primMax (also lrl_scene_rebuild_bvh)
+int runDeviceBuild(LrlContext* c, uint32_t prims, uint32_t& recCount, uint32_t& depth) {
+    auto asf = [](uint32_t v) { float f; std::memcpy(&f, &v, 4); return f; };
     int rc;
     recCount = std::max(prims, 1u);
     if ((rc = ensure(c, c->nodes, size_t(recCount) * 64))) return rc;
@@ -420,7 +433,7 @@ int buildOnDevice(LrlContext* c, const LrlSceneView* s, uint32_t prims, uint32_t
     if (info[0] + 1 > LRL_MAX_BVH_DEPTH) return fail(c, LRL_ERR_BVH_DEPTH, "device-built BVH deeper than LRL_MAX_BVH_DEPTH");
     depth = info[0];
     c->node4Depth = info[1];
-    release(c->buildScratch);      // the tree is built: only the records stay
+    if (scratch > (64u << 20)) release(c->buildScratch);      // the tree is built: only the records stay (small scratch is kept for rebuilds)
     return LRL_OK;
 }
 
@@ -489,6 +502,7 @@ int lrl_scene_upload(LrlContext* c, const LrlSceneView* s) {
     int rc = deviceBuild ? LRL_OK : validateBVH(c, s, depth);
     if (rc) return rc;
     c->haveScene = false;
+    c->deviceBuilt = false;
     c->waterGX = c->waterGY = 0;      // a new scene: lrl_water_init again
 
     // nodes: the reference's 64-B own-box records -> 64-B inner records that hold both children's boxes
@@ -627,6 +641,8 @@ int lrl_scene_upload(LrlContext* c, const LrlSceneView* s) {
         if (std::getenv("LRL_DEBUG")) std::fprintf(stderr, "lrl: device-built tree over %llu primitives: %u records, height %u, four-wide height %u\n",
                                                    (unsigned long long)primTotal, recCount, depth, c->node4Depth);
     }
+    c->deviceBuilt = deviceBuild;
+    c->primTotal = uint32_t(primTotal);
     c->nodeNum = deviceBuild ? uint32_t(2 * primTotal - 1) : s->bvhNodeNum;
     c->recNum = recCount;
     c->bvhDepth = depth;
@@ -1083,6 +1099,19 @@ int lrl_timing_end(LrlContext* c, double* totalMs, uint32_t* launches) {
     return LRL_OK;
 }
 
+int lrl_scene_rebuild_bvh(LrlContext* c) {
+    if (!c) return LRL_ERR_INVALID_ARG;
+    if (!c->haveScene) return fail(c, LRL_ERR_NO_SCENE, "no scene uploaded");
+    if (!c->deviceBuilt) return fail(c, LRL_ERR_INVALID_ARG, "the tree came from the caller (LrlSceneView.bvh): it is never rebuilt here");
+    HIP_TRY(c, hipSetDevice(c->device));
+    uint32_t recCount = 0, depth = 0;
+    const int rc = runDeviceBuild(c, c->primTotal, recCount, depth);
+    if (rc) return rc;
+    c->recNum = recCount;
+    c->bvhDepth = depth;
+    return LRL_OK;
+}
+
 int lrl_water_init(LrlContext* c, uint32_t gx, uint32_t gy, float k, float dt, const LrlWaterPoint* points, uint32_t firstTriangle,
                    const LrlTriangle* triangles) {
     if (!c || !points || !triangles) return LRL_ERR_INVALID_ARG;
@@ -1113,6 +1142,9 @@ int lrl_water_step(LrlContext* c, uint32_t substeps) {
                                     static_cast<LrlTriangle*>(c->waterTris.p), c->stream));
     HIP_TRY(c, lrl_launch_triangle_pre(static_cast<const LrlTriangle*>(c->waterTris.p), static_cast<const uint32_t*>(c->waterMat.p), c->waterFirst, count,
                                        static_cast<float4*>(c->triHot.p), static_cast<LrlTriCold*>(c->triCold.p), c->stream));
+    if (c->deviceBuilt)      // keep the boxes current for lrl_scene_rebuild_bvh
+        HIP_TRY(c, lrl_launch_triangle_boxes(static_cast<const LrlTriangle*>(c->waterTris.p), c->waterFirst, count, static_cast<float4*>(c->primMin.p),
+                                             static_cast<float4*>(c->primMax.p), c->stream));
     return LRL_OK;
 }
 

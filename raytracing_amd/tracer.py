@@ -19,7 +19,7 @@ EXPORTS = [
     "lrl_create", "lrl_destroy", "lrl_last_error", "lrl_version", "lrl_scene_upload", "lrl_scene_update_triangles",
     "lrl_scene_read_triangles_gpu", "lrl_scene_read_circles", "lrl_set_camera", "lrl_set_decay_origin", "lrl_compute_decay_origin",
     "lrl_render", "lrl_render_async", "lrl_sync", "lrl_get_counters", "lrl_last_kernel_ms", "lrl_scene_device_bytes",
-    "lrl_timing_begin", "lrl_timing_end", "lrl_water_init", "lrl_water_step", "lrl_water_read",
+    "lrl_timing_begin", "lrl_timing_end", "lrl_water_init", "lrl_water_step", "lrl_water_read", "lrl_scene_rebuild_bvh",
 ]
 
 
@@ -50,6 +50,7 @@ def lib():
         L.lrl_timing_end.argtypes = [C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_uint32)]
         L.lrl_water_init.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32, C.c_float, C.c_float, C.c_void_p, C.c_uint32, C.c_void_p]
         L.lrl_water_step.argtypes = [C.c_void_p, C.c_uint32]
+        L.lrl_scene_rebuild_bvh.argtypes = [C.c_void_p]
         L.lrl_water_read.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
         _lib = L
     return _lib
@@ -121,6 +122,10 @@ class Tracer:
         self._water = (gx, gy)
         self._ck(self._L.lrl_water_init(self._ctx, C.c_uint32(gx), C.c_uint32(gy), C.c_float(k), C.c_float(dt), w.ctypes.data_as(C.c_void_p),
                                         C.c_uint32(first_triangle), t.ctypes.data_as(C.c_void_p)))
+
+    def rebuild_bvh(self):
+        """Rebuild a device-built tree from the current triangles (after update_triangles / water_step)."""
+        self._ck(self._L.lrl_scene_rebuild_bvh(self._ctx))
 
     def water_step(self, substeps):
         self._ck(self._L.lrl_water_step(self._ctx, C.c_uint32(substeps)))

@@ -465,3 +465,38 @@ def test_device_built_bvh_counts_and_edge_cases(tracer, default_model):
         assert imgs[0][..., :3].max() > 0
         for im in imgs[1:]:
             assert image_stats(im, imgs[0])["rmse"] <= RMSE_FAST
+
+
+def test_rebuild_of_a_device_built_tree_follows_the_water(tracer, pool_model):
+    """Device-built tree over the Pool scene: after lrl_water_step the triangles have left the boxes the tree was built
+    with; lrl_scene_rebuild_bvh builds it again from the current triangles and the image is the oracle's image of the moved
+    scene (the oracle walks the host tree, whose tall boxes hold every height).  A caller-supplied tree is never rebuilt."""
+    from raytracing_amd.tracer import TraceError
+    gx, gy = scenes.POOL_GRID
+    k, dt = scenes.POOL_WATER
+    nw = 2 * (gx - 1) * (gy - 1)
+    tris = pool_model.arrays()["triangles"]
+    w0 = scenes.pool_water_points(pool_model)
+    g = load_golden("pool_viewB_192")
+    tracer.scene_upload(pool_model.scene_view())
+    with pytest.raises(TraceError):
+        tracer.rebuild_bvh()
+    tracer.scene_upload(without_tree(pool_model))
+    tracer.set_camera(g["trans"], g["width"], g["height"])
+    tracer.set_decay_origin((0, 0, 0, 1))
+    tracer.water_init(gx, gy, k, dt, w0, 0, tris[:nw])
+    tracer.water_step(200)
+    tracer.rebuild_bvh()
+    ow = O.water_run(w0, gx, gy, k, dt, 200)
+    ot = O.water_sync(ow, gx, gy, tris)
+    oimg, ohits, _ = O.render(view_with(pool_model, ot), g["trans"], g["width"], g["height"], max_depth=8, variant=abi.VARIANT_POOL, threads=8)
+    for mode in (abi.MODE_PARITY, abi.MODE_FAST):
+        img, hits = tracer.render(max_depth=8, variant=abi.VARIANT_POOL, mode=mode)
+        assert (hits == ohits).all(axis=-1).mean() >= 0.9995, mode
+        assert image_stats(img, oimg)["rmse"] <= (RMSE_PARITY if mode == abi.MODE_PARITY else RMSE_FAST), mode
+    # and again after more steps and a host-side triangle update
+    tracer.water_step(100)
+    tracer.update_triangles(0, ot[:nw])          # back to the state after 200 steps, through the host path
+    tracer.rebuild_bvh()
+    img, hits = tracer.render(max_depth=8, variant=abi.VARIANT_POOL, mode=abi.MODE_PARITY)
+    assert (hits == ohits).all(axis=-1).mean() >= 0.9995 and image_stats(img, oimg)["rmse"] <= RMSE_PARITY
