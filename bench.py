@@ -45,11 +45,12 @@ def main():
     ap.add_argument("--builder", default="reference", choices=["reference", "median", "device"],
                     help="who builds the BVH: the restated reference builder (host, default), a median-split host builder, or the library on the device")
     ap.add_argument("--subdivisions", type=int, default=2)
-    ap.add_argument("--width", type=int, default=1920)
-    ap.add_argument("--height", type=int, default=1080)
+    ap.add_argument("--width", type=int, default=0, help="0 = the workload's own: 1920 (c1: 1024)")
+    ap.add_argument("--height", type=int, default=0, help="0 = the workload's own: 1080 (c1: 1024)")
     ap.add_argument("--depth", type=int, default=0, help="RayTraceDepth (0 = the workload's own: 4 for c2, 8 for c3)")
-    ap.add_argument("--workload", default="c2", choices=["c2", "c3"],
-                    help="c2 (default, the headline metric's configuration) | c3: Pool demo scene, Pool shader variant, 64 spp (SURVEY 8d)")
+    ap.add_argument("--workload", default="c2", choices=["c1", "c2", "c3"],
+                    help="c2 (default, the headline metric's configuration) | c1: the reference's default BVH scene as shipped, 1024 x 1024, "
+                         "RayTraceDepth 10 | c3: Pool demo scene, Pool shader variant, 64 spp (SURVEY 8d)")
     ap.add_argument("--grid", type=int, default=1, help="c2 only: grid x grid replicated copies of the mesh (towards C5: 9 -> 100.5 M triangles)")
     ap.add_argument("--spp", type=int, default=0, help="samples per pixel (0 = the workload's own: 1 for c2, 64 for c3)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -87,16 +88,20 @@ def main():
 
     # ---- scene: built on the host by the restated reference library, uploaded once ----
     t0 = time.time()
-    c3 = a.workload == "c3"
-    a.depth = a.depth or (8 if c3 else 4)
+    c1, c3 = a.workload == "c1", a.workload == "c3"
+    a.width = a.width or (1024 if c1 else 1920)
+    a.height = a.height or (1024 if c1 else 1080)
+    a.depth = a.depth or (10 if c1 else 8 if c3 else 4)
     a.spp = a.spp or (64 if c3 else 1)
     variant = abi.VARIANT_POOL if c3 else abi.VARIANT_BVH
     if c3:
         m = scenes.pool(builder="reference" if a.builder == "device" else a.builder)      # (the Pool model always builds its tree; not handed over)
+    elif c1:
+        m = scenes.bvh_default(builder="reference" if a.builder == "device" else a.builder)
     else:
         m = scenes.mesh_scene(subdivisions=a.subdivisions, builder="none" if a.builder == "device" else a.builder, grid=a.grid)
     build_s = time.time() - t0
-    info = m.bvh_info() if a.builder != "device" or c3 else {"nodes": 0, "max_depth": 0}
+    info = m.bvh_info() if a.builder != "device" or c3 or c1 else {"nodes": 0, "max_depth": 0}
     W, H = a.width, a.height
     trans = m.camera(H)
     view = m.scene_view()
@@ -206,7 +211,8 @@ def main():
             "metric": "Mrays/s (whole node) at 1080p 4-bounce", "value": round(value, 2), "unit": "Mrays/s", "n_gpus": world,
             "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(ms_per_step, 4), "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": (f"C3: Pool demo scene ({view.num.triangleNum} triangles, water at rest), Pool shader variant, " if c3 else
+            "config": {"workload": (f"C1: the reference's default BVH scene ({view.num.triangleNum} triangles + spheres, discs, cylinders, cones), " if c1 else
+                                    f"C3: Pool demo scene ({view.num.triangleNum} triangles, water at rest), Pool shader variant, " if c3 else
                                     f"C2: Stanford bunny x{a.subdivisions} subdivisions{f', {a.grid}x{a.grid} copies' if a.grid > 1 else ''} ({view.num.triangleNum} triangles) + ground disc + 1 light, ") +
                                    f"{W}x{H}, {a.spp} spp per GPU, RayTraceDepth {a.depth}",
                        "bvh_builder": a.builder, "bvh_nodes": info["nodes"], "bvh_depth": info["max_depth"], "arithmetic": a.mode,

@@ -112,6 +112,9 @@ enum { LRL_CTR_PRIMARY = 0, LRL_CTR_REFLECT, LRL_CTR_REFRACT, LRL_CTR_SHADOW, LR
 #ifndef LRL_WF_LEAN_WAVES
 #define LRL_WF_LEAN_WAVES 8       /* __launch_bounds__ waves per SIMD of the lean trace kernel (64 VGPRs) */
 #endif
+#ifndef LRL_LEAN_BLOCK_WAVES
+#define LRL_LEAN_BLOCK_WAVES 4    /* waves per workgroup of the lean trace kernel in sparse iterations (independent of each other) */
+#endif
 #ifndef LRL_LEAN_STACK
 #define LRL_LEAN_STACK 8          /* its LDS rows of parked children per lane (8 rows + 1: 32 waves per CU fit in 160 KB) */
 #endif
@@ -134,7 +137,6 @@ struct WFrame {
     uint32_t sample;         // sample index rendered by this pass
     uint32_t overflowEntries;   // per-lane entries of `overflow` (0: the LDS stack always suffices)
     uint32_t tilesY;         // rows of tiles
-    uint32_t xcdBlock;       // lean trace kernel: edge (in tiles) of the square pixel blocks dealt out to the 8 XCDs; 0 = workgroup i takes word i
     float4* answer;          // xyz accumulated colour, w = v of the pending light terms
     float4* ratio;           // ratioNow
     float4* decay;           // decayNow (kept only when a material transmits: otherwise it never leaves decayOrigin)
@@ -171,7 +173,7 @@ struct WFrame {
 LRL_WF_DECLARE(lrl_parity)
 LRL_WF_DECLARE(lrl_fast)
 namespace lrl_fast {
-hipError_t wfLaunchTraceLean(const KScene& sc, const WFrame& wf, hipStream_t stream);
+hipError_t wfLaunchTraceLean(const KScene& sc, const WFrame& wf, bool sparse, hipStream_t stream);   // sparse: few rays in many words (larger workgroups)
 hipError_t wfLaunchTraceSwarm(const KScene& sc, const WFrame& wf, uint32_t waves, hipStream_t stream);
 }
 

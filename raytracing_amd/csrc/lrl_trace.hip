@@ -772,8 +772,6 @@ static int renderWavefront(LrlContext* c, const LrlRenderParams* p, const KScene
     char* base = static_cast<char*>(c->wfArena.p);
     WFrame wf{};
     wf.P = uint32_t(P); wf.words = words; wf.tilesX = tilesX; wf.tilesY = tilesY; wf.overflowEntries = ovfN;
-    const char* xcd = std::getenv("LRL_XCD_BLOCK");
-    wf.xcdBlock = xcd ? uint32_t(std::atoi(xcd)) : 0u;
     float4* st = reinterpret_cast<float4*>(base + oState);
     wf.answer = st; wf.ratio = st + P; wf.decay = st + 2 * P; wf.hit = st + 3 * P;
     wf.pendA = st + 4 * P; wf.pendB = st + 5 * P;
@@ -792,6 +790,8 @@ static int renderWavefront(LrlContext* c, const LrlRenderParams* p, const KScene
     // run out and the wave-per-ray kernel becomes the slow part, so the threshold of an iteration follows the number of rays
     // that iteration handed over in the last finished sample: doubled (x4 when far beyond the slots) while (nearly) all
     // slots were asked for, halved back towards its default below 1/8.  LRL_ADAPT=0 pins the defaults.
+    const char* sparseEnv = std::getenv("LRL_SPARSE_FROM");      // first iteration traced with the larger workgroups
+    const uint32_t sparseFrom = sparseEnv ? uint32_t(std::atoi(sparseEnv)) : 5u;      // (measured: C2 best with none of its 5, C1 with 8 of its 56, C3 with 4 of its 10)
     const bool adapt = !(std::getenv("LRL_ADAPT") && std::atoi(std::getenv("LRL_ADAPT")) == 0);
     auto baseThr = [&](uint32_t i) { return i < 2 ? handoverEarly : handoverLate; };   // few rays left after the first bounces: the waves are free sooner
     if (c->handoverThr.empty() || !adapt) {
@@ -847,7 +847,7 @@ static int renderWavefront(LrlContext* c, const LrlRenderParams* p, const KScene
         if (special) {
             wf.contCount = contCounts + (iter < LRL_WF_MAX_ITERATIONS ? iter : 0);
             wf.handoverTrips = c->handoverThr[std::min(iter, LRL_FEEDBACK_ITERS - 1)];
-            HIP_TRY(c, lrl_fast::wfLaunchTraceLean(k, wf, stream));
+            HIP_TRY(c, lrl_fast::wfLaunchTraceLean(k, wf, iter >= sparseFrom, stream));
             if (wf.handoverTrips) HIP_TRY(c, lrl_fast::wfLaunchTraceSwarm(k, wf, c->swarmGrid[std::min(iter, LRL_FEEDBACK_ITERS - 1)], stream));
         }
         else HIP_TRY(c, fast ? lrl_fast::wfLaunchTrace(k, wf, stream) : lrl_parity::wfLaunchTrace(k, wf, stream));
