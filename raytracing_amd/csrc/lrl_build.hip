@@ -85,9 +85,11 @@ __global__ __launch_bounds__(256) void mortonKernel(const float4* __restrict__ p
     const float hi[3] = {fkeyInv(bounds[3]), fkeyInv(bounds[4]), fkeyInv(bounds[5])};
     const float4 a = pmin[i], b = pmax[i];
     const float c[3] = {0.5f * (a.x + b.x), 0.5f * (a.y + b.y), 0.5f * (a.z + b.z)};
+    // one cell size for the three axes (the longest extent): with per-axis scaling a flat scene would spend every third
+    // bit on slicing its thin direction into pancakes
+    const float ext = fmaxf(fmaxf(hi[0] - lo[0], hi[1] - lo[1]), hi[2] - lo[2]);
     uint32_t q[3];
     for (int k = 0; k < 3; ++k) {
-        const float ext = hi[k] - lo[k];
         const float t = ext > 0.0f ? (c[k] - lo[k]) / ext : 0.0f;
         q[k] = uint32_t(fminf(fmaxf(t * 2097152.0f, 0.0f), 2097151.0f));
     }
