@@ -268,6 +268,40 @@ def test_full_size_properties_1080p(tracer, bunny0_model):
     assert image_stats(stripe, oimg)["rmse"] <= RMSE_PARITY
 
 
+def test_headline_workload_properties(tracer):
+    """bench.py's workload itself (C2: 1 240 960 triangles, 1920x1080, 4 bounces), through properties that need no oracle
+    run of the whole frame: FAST against PARITY (ids, image, ray count), the reference builder's tree against the tree built
+    on the device, idempotence, and the oracle on a 16-row stripe through the middle of the bunny."""
+    m = scenes.mesh_scene(subdivisions=2, builder="reference")
+    W, H = 1920, 1080
+    tr = m.camera(H)
+    view = m.scene_view()
+    res = {}
+    for dev in (False, True):
+        tracer.scene_upload(without_tree(m) if dev else view)
+        tracer.set_camera(tr, W, H)
+        tracer.set_decay_origin((0, 0, 0, 1))
+        for mode in (abi.MODE_PARITY, abi.MODE_FAST):
+            img, hits = tracer.render(max_depth=4, mode=mode, counters=(mode == abi.MODE_PARITY))
+            res[dev, mode] = (img, hits, tracer.counters().rays if mode == abi.MODE_PARITY else None)
+            assert np.isfinite(img).all() and (img[..., :3] >= 0).all() and np.all(img[..., 3] == 1.0)
+        again, _ = tracer.render(max_depth=4, mode=abi.MODE_FAST)
+        assert np.array_equal(again, res[dev, abi.MODE_FAST][0])
+    base_img, base_hits, base_rays = res[False, abi.MODE_PARITY]
+    assert base_rays > 3 * W * H                      # reflections and shadow rays are there
+    for key, (img, hits, rays) in res.items():
+        if key == (False, abi.MODE_PARITY):
+            continue
+        assert (hits == base_hits).all(axis=-1).mean() >= ID_BAR, key
+        assert image_stats(img, base_img)["rmse"] <= RMSE_FAST, key
+        if rays is not None:
+            assert abs(rays - base_rays) <= 1e-4 * base_rays, key
+    r0 = 470
+    oimg, ohits, _ = O.render(view, tr, W, H, max_depth=4, rows=(r0, r0 + 16), threads=8)
+    assert (base_hits[r0:r0 + 16] == ohits).all(axis=-1).mean() >= ID_BAR
+    assert image_stats(base_img[r0:r0 + 16], oimg)["rmse"] <= RMSE_PARITY
+
+
 @pytest.mark.parametrize("name", ["bvh_viewB_256", "bvh_viewB_128_spp4", "bvh_inside_glass_128"])
 def test_wavefront_and_megakernel_schedules_agree_bit_for_bit(tracer, default_model, name):
     """The wavefront pipeline (default) and the one-launch kernel run the same PARITY arithmetic in a different order of
