@@ -141,6 +141,11 @@ int lrl_render(LrlContext* ctx, const LrlRenderParams* params,
 int lrl_render_async(LrlContext* ctx, const LrlRenderParams* params, float* rgba_out_dev, uint32_t* hit_out_dev,
                      void* hip_stream);
 int lrl_sync(LrlContext* ctx);
+/* The image the reference shows: its fragment output lands in the default framebuffer, RGBA8, clamped to [0, 1] (SURVEY 8b
+ * "Output"; BVH/BVH.cpp:42 draws into the window).  Converts `pixels` RGBA32F values on the device (rgba_dev: e.g. the output
+ * of lrl_render_async) to 8-bit unsigned normalised values, round(clamp(v, 0, 1) * 255) as OpenGL's float -> unorm conversion,
+ * into out_dev (4 bytes per pixel, device memory), on the context's stream.  For A/B against a screenshot of the reference. */
+int lrl_quantize_rgba8(LrlContext* ctx, const float* rgba_dev, uint8_t* out_dev, uint64_t pixels);
 
 /* ---- measurement ---- */
 int lrl_get_counters(LrlContext* ctx, LrlCounters* out);   /* of the last render with LRL_FLAG_COUNTERS */

@@ -122,6 +122,23 @@ __global__ __launch_bounds__(LRL_WATER_THREADS) void waterRunKernel(float4* __re
 
 }  // namespace lrl_parity
 
+namespace lrl_parity {
+// float -> unorm8 as OpenGL converts a fragment colour for an RGBA8 framebuffer: clamp to [0, 1], scale by 255, round to nearest
+__global__ __launch_bounds__(256) void quantizeKernel(const float4* __restrict__ in, uchar4* __restrict__ out, unsigned long long pixels) {
+    const unsigned long long i = blockIdx.x * 256ull + threadIdx.x;
+    if (i >= pixels) return;
+    const float4 v = in[i];
+    auto q = [](float x) { return (unsigned char)rintf(fminf(fmaxf(x, 0.0f), 1.0f) * 255.0f); };      // NaN -> 0 (fmaxf returns the other operand)
+    out[i] = make_uchar4(q(v.x), q(v.y), q(v.z), q(v.w));
+}
+}  // namespace lrl_parity
+
+hipError_t lrl_launch_quantize(const float4* in, uchar4* out, unsigned long long pixels, hipStream_t stream) {
+    if (!pixels) return hipSuccess;
+    hipLaunchKernelGGL(lrl_parity::quantizeKernel, dim3((unsigned)((pixels + 255) / 256)), dim3(256), 0, stream, in, out, pixels);
+    return hipGetLastError();
+}
+
 hipError_t lrl_launch_water_run(float4* water, uint32_t gx, uint32_t gy, float k, float dt, uint32_t substeps, LrlTriangle* tris, hipStream_t stream) {
     hipLaunchKernelGGL(lrl_parity::waterRunKernel, dim3(1), dim3(LRL_WATER_THREADS), size_t(gx) * gy * 4, stream, water, gx, gy, k, dt, substeps, tris);
     return hipGetLastError();

@@ -193,6 +193,7 @@ hipError_t lrl_launch_triangle_boxes(const LrlTriangle* in, uint32_t first, uint
 size_t lrl_build_scratch_bytes(uint32_t n);
 hipError_t lrl_build_bvh(const float4* pmin, const float4* pmax, uint32_t n, float4* recs, uint4* node4, void* scratch, size_t scratchBytes,
                          uint32_t* infoDev, hipStream_t stream);
+hipError_t lrl_launch_quantize(const float4* in, uchar4* out, unsigned long long pixels, hipStream_t stream);   // RGBA32F -> RGBA8 (unorm)
 // Pool water simulation: `substeps` x (acceleration, position) on gx * gy points {z, v, a, blank} (<= 16384), then the
 // heights into the corners of the 2 (gx-1) (gy-1) water triangles `tris` (origin records on the device; NULL: no sync)
 hipError_t lrl_launch_water_run(float4* water, uint32_t gx, uint32_t gy, float k, float dt, uint32_t substeps, LrlTriangle* tris, hipStream_t stream);

@@ -1024,6 +1024,13 @@ int lrl_sync(LrlContext* c) {
     return LRL_OK;
 }
 
+int lrl_quantize_rgba8(LrlContext* c, const float* rgbaDev, uint8_t* outDev, uint64_t pixels) {
+    if (!c || (pixels && (!rgbaDev || !outDev)) || pixels > (1ull << 32)) return LRL_ERR_INVALID_ARG;
+    HIP_TRY(c, hipSetDevice(c->device));
+    HIP_TRY(c, lrl_launch_quantize(reinterpret_cast<const float4*>(rgbaDev), reinterpret_cast<uchar4*>(outDev), pixels, c->stream));
+    return LRL_OK;
+}
+
 int lrl_render(LrlContext* c, const LrlRenderParams* p, float* rgba, uint32_t* hit) {
     uint32_t rows = 0;
     int rc = checkRender(c, p, rows);

@@ -19,7 +19,7 @@ EXPORTS = [
     "lrl_create", "lrl_destroy", "lrl_last_error", "lrl_version", "lrl_scene_upload", "lrl_scene_update_triangles",
     "lrl_scene_read_triangles_gpu", "lrl_scene_read_circles", "lrl_set_camera", "lrl_set_decay_origin", "lrl_compute_decay_origin",
     "lrl_render", "lrl_render_async", "lrl_sync", "lrl_get_counters", "lrl_last_kernel_ms", "lrl_scene_device_bytes",
-    "lrl_timing_begin", "lrl_timing_end", "lrl_water_init", "lrl_water_step", "lrl_water_read", "lrl_scene_rebuild_bvh",
+    "lrl_timing_begin", "lrl_timing_end", "lrl_water_init", "lrl_water_step", "lrl_water_read", "lrl_scene_rebuild_bvh", "lrl_quantize_rgba8",
 ]
 
 
@@ -51,6 +51,7 @@ def lib():
         L.lrl_water_init.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32, C.c_float, C.c_float, C.c_void_p, C.c_uint32, C.c_void_p]
         L.lrl_water_step.argtypes = [C.c_void_p, C.c_uint32]
         L.lrl_scene_rebuild_bvh.argtypes = [C.c_void_p]
+        L.lrl_quantize_rgba8.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64]
         L.lrl_water_read.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
         _lib = L
     return _lib
@@ -173,6 +174,10 @@ class Tracer:
         p = self._params(max_depth, variant, mode, flags, jitter, rows, samples)
         self._ck(self._L.lrl_render_async(self._ctx, C.byref(p), C.c_void_p(out_ptr), C.c_void_p(hit_ptr) if hit_ptr else None,
                                           C.c_void_p(stream) if stream else None))
+
+    def quantize_rgba8(self, rgba_ptr, out_ptr, pixels):
+        """RGBA32F -> RGBA8 on the device (device pointers), on the context's stream."""
+        self._ck(self._L.lrl_quantize_rgba8(self._ctx, C.c_void_p(rgba_ptr), C.c_void_p(out_ptr), C.c_uint64(pixels)))
 
     def sync(self):
         self._ck(self._L.lrl_sync(self._ctx))

@@ -11,7 +11,7 @@ from raytracing_amd import tracer
 def declared_symbols():
     text = open(os.path.join(REPO, "include", "lrl_trace.h")).read()
     text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
-    return sorted(set(re.findall(r"\b(lrl_[a-z_]+)\s*\(", text)))
+    return sorted(set(re.findall(r"\b(lrl_[a-z0-9_]+)\s*\(", text)))
 
 
 def test_header_and_wrapper_agree():

@@ -534,3 +534,21 @@ def test_rebuild_of_a_device_built_tree_follows_the_water(tracer, pool_model):
     tracer.rebuild_bvh()
     img, hits = tracer.render(max_depth=8, variant=abi.VARIANT_POOL, mode=abi.MODE_PARITY)
     assert (hits == ohits).all(axis=-1).mean() >= 0.9995 and image_stats(img, oimg)["rmse"] <= RMSE_PARITY
+
+
+def test_quantize_rgba8_is_opengl_float_to_unorm(tracer):
+    """lrl_quantize_rgba8 = round(clamp(v, 0, 1) * 255), ties to even, NaN -> 0: the conversion the reference's colours
+    undergo on their way into its RGBA8 window."""
+    import torch
+    rng = np.random.default_rng(5)
+    v = rng.uniform(-0.5, 1.5, size=(1000, 4)).astype(np.float32)
+    v[:8] = [[0, 1, 0.5, 0.25], [np.nan, np.inf, -np.inf, -0.0], [0.5 / 255, 1.5 / 255, 2.5 / 255, 254.5 / 255],
+             [1e-9, 1 - 1e-9, 0.999999, 0.0019607], [2, -2, 1.0000001, 0.4999], [127.5 / 255, 128.5 / 255, 0.1, 0.9],
+             [0.3, 0.6, 0.7, 1.0], [0.2, 0.4, 0.8, 0.0]]
+    src = torch.from_numpy(v).cuda()
+    dst = torch.zeros((1000, 4), dtype=torch.uint8, device="cuda")
+    tracer.quantize_rgba8(src.data_ptr(), dst.data_ptr(), 1000)
+    tracer.sync()
+    with np.errstate(invalid="ignore"):
+        want = np.rint(np.clip(np.nan_to_num(v, nan=0.0, posinf=1.0, neginf=0.0), 0, 1).astype(np.float32) * np.float32(255)).astype(np.uint8)
+    assert np.array_equal(dst.cpu().numpy(), want)
