@@ -120,6 +120,7 @@ enum { LRL_CTR_PRIMARY = 0, LRL_CTR_REFLECT, LRL_CTR_REFRACT, LRL_CTR_SHADOW, LR
 #endif
 #ifndef LRL_SWARM_CAP
 #define LRL_SWARM_CAP 1024         /* frontier entries of the wave-per-ray continuation kernel (LDS) */
+#define LRL_WORK_COUNTERS 4u
 #endif
 #define LRL_WF_SLOT_ALIGN (64u * LRL_WF_CHUNK_WORDS > 256u ? 64u * LRL_WF_CHUNK_WORDS : 256u)
 
@@ -152,7 +153,11 @@ struct WFrame {
     uint32_t* alive;         // [iteration]: set to 1 by the shade kernel while any path is unfinished
     // hand-over of long chains (lrl_lean.inc -> wfTraceSwarmKernel): a ray still going after `handoverTrips` trips leaves
     // its pending work here and a whole wave finishes it
+    uint32_t* contWork;      // LRL_WORK_COUNTERS counters, 128 B apart: frontier entries the hand-over kernel tested in this iteration
     uint32_t handoverTrips;  // 0: never hand over
+    uint32_t handoverStep;   // trips between the checks after the first
+    uint32_t handoverRefs;   // at the first check only the rays with at least this many pending refs leave (the others are nearly done)
+    uint32_t handoverLanes;  // a wave hands its rays over only when at most this many lanes are still going
     uint32_t contSlots;      // capacity of contHead / contRefs
     uint32_t contStride;     // refs per slot (>= deepest stack + 1)
     uint32_t* contCount;     // slots taken by this launch (zero before it)
@@ -174,7 +179,7 @@ LRL_WF_DECLARE(lrl_parity)
 LRL_WF_DECLARE(lrl_fast)
 namespace lrl_fast {
 hipError_t wfLaunchTraceLean(const KScene& sc, const WFrame& wf, bool sparse, hipStream_t stream);   // sparse: few rays in many words (larger workgroups)
-hipError_t wfLaunchTraceSwarm(const KScene& sc, const WFrame& wf, uint32_t waves, hipStream_t stream);
+hipError_t wfLaunchTraceSwarm(const KScene& sc, const WFrame& wf, uint32_t waves, uint32_t group, hipStream_t stream);
 }
 
 // kernels_parity.hip / kernels_fast.hip

@@ -68,6 +68,7 @@ struct LrlContext {
     // sample (pinned copy, read when its event has completed: never waited for)
     uint32_t* contHost = nullptr;
     hipEvent_t evCont = nullptr;
+    std::vector<float> workPerRay;      // per iteration: frontier entries per handed-over ray, last feedback
     uint32_t contIters = 0;             // words of contHost in flight / ready
     std::vector<LrlTrans> transUploaded;   // what transDev holds (per-sample cameras of the last render)
     std::vector<uint32_t> handoverThr;  // per iteration index; empty until first use
@@ -483,6 +484,7 @@ int lrl_destroy(LrlContext* c) {
 }
 
 int lrl_scene_upload(LrlContext* c, const LrlSceneView* s) {
+    if (c) c->handoverThr.clear();       // the hand-over thresholds start again with a new scene
     if (!c || !s) return LRL_ERR_INVALID_ARG;
     HIP_TRY(c, hipSetDevice(c->device));
     const LrlGeometryNum& g = s->num;
@@ -757,8 +759,9 @@ static int renderWavefront(LrlContext* c, const LrlRenderParams* p, const KScene
     auto take = [&](size_t bytes) { size_t o = off; off += (bytes + 255) / 256 * 256; return o; };
     const size_t oState = take(P * 16 * 6), oFlags = take(P * 4), oRayQ = take(P * (1 + size_t(L)) * 32), oMaskC = take(size_t(words) * 8),
                  oMaskS = take(size_t(words) * 8), oRefr = take(P * 64 * refrEntries), oOvf = take(ovfBytes),
-                 oAlive = take(LRL_WF_MAX_ITERATIONS * 4 * 2);
-    const uint32_t contSlots = 65536, contStride = stackNeed + 1;
+                 oAlive = take(LRL_WF_MAX_ITERATIONS * 4 * 2 + LRL_FEEDBACK_ITERS * LRL_WORK_COUNTERS * 128);
+    const char* slotsEnv = std::getenv("LRL_CONT_SLOTS");
+    const uint32_t contSlots = slotsEnv ? std::max(1024u, uint32_t(std::atoi(slotsEnv))) : 262144u, contStride = stackNeed + 1;
     const size_t oContHead = take(size_t(contSlots) * 16), oContRefs = take(size_t(contSlots) * contStride * 4);
     int rc = ensure(c, c->wfArena, off);
     if (rc) return rc;
@@ -766,7 +769,7 @@ static int renderWavefront(LrlContext* c, const LrlRenderParams* p, const KScene
         HIP_TRY(c, hipHostMalloc(reinterpret_cast<void**>(&c->aliveHost), LRL_WF_MAX_ITERATIONS * 4, hipHostMallocDefault));
         HIP_TRY(c, hipEventCreateWithFlags(&c->evIter[0], hipEventDisableTiming));
         HIP_TRY(c, hipEventCreateWithFlags(&c->evIter[1], hipEventDisableTiming));
-        HIP_TRY(c, hipHostMalloc(reinterpret_cast<void**>(&c->contHost), LRL_FEEDBACK_ITERS * 4, hipHostMallocDefault));
+        HIP_TRY(c, hipHostMalloc(reinterpret_cast<void**>(&c->contHost), LRL_FEEDBACK_ITERS * 4 + LRL_FEEDBACK_ITERS * LRL_WORK_COUNTERS * 128, hipHostMallocDefault));
         HIP_TRY(c, hipEventCreateWithFlags(&c->evCont, hipEventDisableTiming));
     }
     char* base = static_cast<char*>(c->wfArena.p);
@@ -783,31 +786,53 @@ static int renderWavefront(LrlContext* c, const LrlRenderParams* p, const KScene
     wf.overflow = reinterpret_cast<uint2*>(base + oOvf);
     wf.alive = reinterpret_cast<uint32_t*>(base + oAlive);
     uint32_t* const contCounts = wf.alive + LRL_WF_MAX_ITERATIONS;      // one per iteration, zeroed with `alive`
+    uint32_t* const contWorkAll = contCounts + LRL_WF_MAX_ITERATIONS;   // [iteration < LRL_FEEDBACK_ITERS][LRL_WORK_COUNTERS] 128 B apart, zeroed with `alive`
     const char* ho = std::getenv("LRL_HANDOVER");
     const char* hoLate = std::getenv("LRL_HANDOVER_LATE");
-    const uint32_t handoverEarly = ho ? uint32_t(std::atoi(ho)) : 64u, handoverLate = hoLate ? uint32_t(std::atoi(hoLate)) : 32u;
-    // The hand-over pays while the long rays are few.  Where most rays are long (Pool: flat tree of tall boxes) the slots
-    // run out and the wave-per-ray kernel becomes the slow part, so the threshold of an iteration follows the number of rays
-    // that iteration handed over in the last finished sample: doubled (x4 when far beyond the slots) while (nearly) all
-    // slots were asked for, halved back towards its default below 1/8.  LRL_ADAPT=0 pins the defaults.
+    const uint32_t handoverEarly = ho ? uint32_t(std::atoi(ho)) : 48u, handoverLate = hoLate ? uint32_t(std::atoi(hoLate)) : 16u;
+    // The hand-over pays for rays with much work left.  Where most rays are of middling length (Pool: flat tree of tall
+    // boxes) the slots run out, or the rays that leave are nearly done and cost more to move than to finish, so the
+    // threshold of an iteration follows what that iteration did in the last finished sample: doubled (x4 when far beyond
+    // the slots) while (nearly) all slots were asked for or the handed-over rays needed fewer than LRL_WORK_LOW frontier
+    // entries each.  A ratchet: thresholds that came back down made the Pool oscillate between two states from sample to
+    // sample (160 ms a frame against 150 for any pinned state); a new scene starts from the defaults.  LRL_ADAPT=0 pins them.
+    // lanes per handed-over ray: groups of 16 when a group's share of the frontier holds the hand-over plus a depth-first
+    // descent (lrl_lean.inc), else a wave per ray
+    const char* groupEnv = std::getenv("LRL_SWARM_GROUP");
+    uint32_t swarmGroup = groupEnv ? uint32_t(std::atoi(groupEnv)) : 16u;
+    if (swarmGroup != 8 && swarmGroup != 16 && swarmGroup != 32) swarmGroup = 64;
+    if (swarmGroup != 64 && 2 * contStride + 3 * swarmGroup > 256) swarmGroup = 64;
     const char* sparseEnv = std::getenv("LRL_SPARSE_FROM");      // first iteration traced with the larger workgroups
     const uint32_t sparseFrom = sparseEnv ? uint32_t(std::atoi(sparseEnv)) : 5u;      // (measured: C2 best with none of its 5, C1 with 8 of its 56, C3 with 4 of its 10)
     const bool adapt = !(std::getenv("LRL_ADAPT") && std::atoi(std::getenv("LRL_ADAPT")) == 0);
-    auto baseThr = [&](uint32_t i) { return i < 2 ? handoverEarly : handoverLate; };   // few rays left after the first bounces: the waves are free sooner
-    if (c->handoverThr.empty() || !adapt) {
+    std::vector<uint32_t> thrList;                               // LRL_HANDOVER_LIST=a,b,c,...: one threshold per iteration (the last repeats)
+    if (const char* tl = std::getenv("LRL_HANDOVER_LIST")) for (const char* q = tl; *q;) { thrList.push_back(uint32_t(std::strtoul(q, const_cast<char**>(&q), 10))); if (*q == ',') ++q; else break; }
+    auto baseThr = [&](uint32_t i) { return !thrList.empty() ? thrList[std::min<size_t>(i, thrList.size() - 1)] : i < 2 ? handoverEarly : i == 2 ? (handoverEarly + handoverLate) / 2 : handoverLate; };   // few rays left after the first bounces: the waves are free sooner (C2: a plateau around 48,48,32,16,16)
+    if (c->handoverThr.empty() || (!adapt && c->handoverThr[0] != baseThr(0))) {
         c->handoverThr.resize(LRL_FEEDBACK_ITERS);
         for (uint32_t i = 0; i < LRL_FEEDBACK_ITERS; ++i) c->handoverThr[i] = baseThr(i);
         c->swarmGrid.assign(LRL_FEEDBACK_ITERS, contSlots);
     }
+    const char* wl = std::getenv("LRL_WORK_LOW");
+    const float workLow = wl ? float(std::atof(wl)) : 12.0f;
+    c->workPerRay.resize(LRL_FEEDBACK_ITERS, 0.0f);
     auto feedback = [&]() {
-        if (!adapt || !c->contIters || hipEventQuery(c->evCont) != hipSuccess) return;
+        if (!c->contIters || hipEventQuery(c->evCont) != hipSuccess) return;
         for (uint32_t i = 0; i < c->contIters; ++i) {
             uint32_t& t = c->handoverThr[i];
             const uint32_t asked = c->contHost[i];
             if (t == 0) continue;
-            if (asked > 4 * 65536u) t = std::min(t * 4, 4096u);
-            else if (asked > 60000u) t = std::min(t * 2, 4096u);
-            else if (asked < 8192u && t > baseThr(i)) t = std::max(baseThr(i), t / 2);
+            uint64_t work = 0;
+            for (uint32_t w = 0; w < LRL_WORK_COUNTERS; ++w) work += c->contHost[LRL_FEEDBACK_ITERS + (size_t(i) * LRL_WORK_COUNTERS + w) * 32];
+            const uint32_t served = std::min(asked, contSlots);
+            const float perRay = served ? 16.0f * float(work) / float(served) : 0.0f;       // one wave in 16 reports
+            c->workPerRay[i] = perRay;
+            // rays that were nearly done when they left (a few frontier entries each) cost more to hand over than to finish
+            // where they were: Pool's rays are all of middling length; the mesh scenes' long rays need 30-40 entries
+            if (!adapt) {}
+            else if (served >= 1024 && perRay < workLow) t = std::min(t * 2, 4096u);
+            else if (asked > 4 * contSlots) t = std::min(t * 4, 4096u);
+            else if (asked > contSlots / 16 * 15) t = std::min(t * 2, 4096u);
             // dispatching 65536 workgroups that find nothing costs ~15 us a launch: twice what was asked for last time is
             // plenty (the kernel strides over the slots whatever the grid)
             c->swarmGrid[i] = std::min(contSlots, std::max(2048u, (2 * asked + 1023u) / 1024u * 1024u));
@@ -815,6 +840,12 @@ static int renderWavefront(LrlContext* c, const LrlRenderParams* p, const KScene
         c->contIters = 0;
     };
     wf.handoverTrips = handoverEarly;
+    const char* lanesEnv = std::getenv("LRL_HANDOVER_LANES");
+    const char* stepEnv = std::getenv("LRL_HANDOVER_STEP");
+    const char* refsEnv = std::getenv("LRL_HANDOVER_REFS");
+    wf.handoverRefs = refsEnv ? uint32_t(std::atoi(refsEnv)) : 1u;
+    wf.handoverLanes = lanesEnv ? uint32_t(std::atoi(lanesEnv)) : 64u;
+    wf.handoverStep = stepEnv ? std::max(1u, uint32_t(std::atoi(stepEnv))) : 8u;
     wf.contSlots = contSlots; wf.contStride = contStride;
     wf.contHead = reinterpret_cast<uint4*>(base + oContHead);
     wf.contRefs = reinterpret_cast<uint32_t*>(base + oContRefs);
@@ -826,7 +857,8 @@ static int renderWavefront(LrlContext* c, const LrlRenderParams* p, const KScene
     const char* tlPath = std::getenv("LRL_TIMELINE");          // diagnostic builds (LRL_DIAG): timeline of ONE trace launch
     const char* tlIter = std::getenv("LRL_TIMELINE_ITER");
     const uint32_t tlWanted = tlIter ? uint32_t(std::atoi(tlIter)) : 0u;
-    if (tlPath && *tlPath && (rc = ensure(c, c->timelineDev, (raysAll / 16) * 48))) return rc;
+    const size_t tlEntries = std::max<size_t>(raysAll / 16, 131072u + 65536u);      // lean: one per mask word; wave-per-ray: 131072 + slot
+    if (tlPath && *tlPath && (rc = ensure(c, c->timelineDev, tlEntries * 48))) return rc;
     // every path ends after at most 2^(maxDepth+1) segments (each hit continues one reflection and parks one refraction)
     // (without a transmitting material nothing is ever parked: a path is primary + at most maxDepth reflections, and its
     // last segment casts no shadow rays, so iteration maxDepth finalises whatever is left)
@@ -847,15 +879,16 @@ static int renderWavefront(LrlContext* c, const LrlRenderParams* p, const KScene
         if (special) {
             wf.contCount = contCounts + (iter < LRL_WF_MAX_ITERATIONS ? iter : 0);
             wf.handoverTrips = c->handoverThr[std::min(iter, LRL_FEEDBACK_ITERS - 1)];
+            wf.contWork = contWorkAll + size_t(std::min(iter, LRL_FEEDBACK_ITERS - 1)) * LRL_WORK_COUNTERS * 32;
             HIP_TRY(c, lrl_fast::wfLaunchTraceLean(k, wf, iter >= sparseFrom, stream));
-            if (wf.handoverTrips) HIP_TRY(c, lrl_fast::wfLaunchTraceSwarm(k, wf, c->swarmGrid[std::min(iter, LRL_FEEDBACK_ITERS - 1)], stream));
+            if (wf.handoverTrips) HIP_TRY(c, lrl_fast::wfLaunchTraceSwarm(k, wf, c->swarmGrid[std::min(iter, LRL_FEEDBACK_ITERS - 1)], swarmGroup, stream));
         }
         else HIP_TRY(c, fast ? lrl_fast::wfLaunchTrace(k, wf, stream) : lrl_parity::wfLaunchTrace(k, wf, stream));
         if (b) HIP_TRY(c, hipEventRecord(b, stream));
         return LRL_OK;
     };
     auto dumpTimeline = [&]() -> int {
-        std::vector<unsigned long long> h((raysAll / 16) * 6);
+        std::vector<unsigned long long> h(tlEntries * 6);
         HIP_TRY(c, hipStreamSynchronize(stream));
         HIP_TRY(c, hipMemcpy(h.data(), c->timelineDev.p, h.size() * 8, hipMemcpyDeviceToHost));
         if (FILE* fp = std::fopen(tlPath, "wb")) { std::fwrite(h.data(), 8, h.size(), fp); std::fclose(fp); }
@@ -868,11 +901,12 @@ static int renderWavefront(LrlContext* c, const LrlRenderParams* p, const KScene
         wf.sample = s;
         if (special) feedback();
         HIP_TRY(c, hipMemsetAsync(wf.alive, 0, size_t(LRL_WF_MAX_ITERATIONS) * 4 + size_t(bound) * 4, stream));
+        if (special) HIP_TRY(c, hipMemsetAsync(contWorkAll, 0, size_t(std::min(bound, LRL_FEEDBACK_ITERS)) * LRL_WORK_COUNTERS * 128, stream));
         HIP_TRY(c, fast ? lrl_fast::wfLaunchGenerate(k, f, wf, stream) : lrl_parity::wfLaunchGenerate(k, f, wf, stream));
         uint32_t iter = 0;
         for (; iter < bound; ++iter) {
             const bool tl = tlPath && *tlPath && iter == tlWanted && s == f.sampleBegin;
-            if (tl) { HIP_TRY(c, hipMemsetAsync(c->timelineDev.p, 0, (raysAll / 16) * 48, stream)); wf.timeline = static_cast<unsigned long long*>(c->timelineDev.p); }
+            if (tl) { HIP_TRY(c, hipMemsetAsync(c->timelineDev.p, 0, tlEntries * 48, stream)); wf.timeline = static_cast<unsigned long long*>(c->timelineDev.p); }
             if ((rc = timedTrace(iter))) return rc;
             if (tl) { wf.timeline = nullptr; if ((rc = dumpTimeline())) return rc; }
             HIP_TRY(c, fast ? lrl_fast::wfLaunchShade(k, f, wf, iter, pool, stream) : lrl_parity::wfLaunchShade(k, f, wf, iter, pool, stream));
@@ -889,17 +923,18 @@ static int renderWavefront(LrlContext* c, const LrlRenderParams* p, const KScene
             if (c->aliveHost[bound - 1] != 0) return fail(c, LRL_ERR_LIMIT, "wavefront pipeline did not finish within its iteration bound");
         }
         iterations += iter;
-        if (special && adapt && c->contIters == 0) {      // (a copy still in flight is left alone)
+        if (special && c->contIters == 0) {      // (a copy still in flight is left alone)
             c->contIters = std::min(iter, LRL_FEEDBACK_ITERS);
             HIP_TRY(c, hipMemcpyAsync(c->contHost, contCounts, size_t(c->contIters) * 4, hipMemcpyDeviceToHost, stream));
+            HIP_TRY(c, hipMemcpyAsync(c->contHost + LRL_FEEDBACK_ITERS, contWorkAll, size_t(c->contIters) * LRL_WORK_COUNTERS * 128, hipMemcpyDeviceToHost, stream));
             HIP_TRY(c, hipEventRecord(c->evCont, stream));
         }
         if (std::getenv("LRL_DEBUG") && special) {
             std::vector<uint32_t> cc(iter);
             HIP_TRY(c, hipStreamSynchronize(stream));
             HIP_TRY(c, hipMemcpy(cc.data(), contCounts, iter * 4, hipMemcpyDeviceToHost));
-            std::fprintf(stderr, "lrl: handed-over rays per iteration (threshold):");
-            for (uint32_t i = 0; i < iter; ++i) std::fprintf(stderr, " %u (%u)", cc[i], c->handoverThr[std::min(i, LRL_FEEDBACK_ITERS - 1)]);
+            std::fprintf(stderr, "lrl: handed-over rays per iteration (threshold, entries per ray at the last feedback):");
+            for (uint32_t i = 0; i < iter; ++i) std::fprintf(stderr, " %u (%u, %.0f)", cc[i], c->handoverThr[std::min(i, LRL_FEEDBACK_ITERS - 1)], c->workPerRay[std::min(i, LRL_FEEDBACK_ITERS - 1)]);
             std::fprintf(stderr, "\n");
         }
     }
