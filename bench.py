@@ -221,7 +221,7 @@ def main():
                        "device_scene_bytes": dbytes},
             "roofline": {"bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBPS, 5), "traffic": traffic, "kernel_ms": round(kernel_ms, 4),
-                         "kernel": "trace kernels of one frame (wfTraceLeanKernel + wfTraceSwarmKernel)" if a.mode == "fast" else "trace kernels of one frame (wfTraceKernel)",
+                         "kernel": "trace kernels of one frame (wfTraceLeanKernel + wfTraceGroupKernel)" if a.mode == "fast" else "trace kernels of one frame (wfTraceKernel)",
                          "launches_per_frame": trace_launches // TRACE_FRAMES, "frame_ms": round(frame_ms, 4),
                          "frame_frac": round(alg_bytes / (frame_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS, 5),
                          "algorithmic_bytes_per_frame": int(alg_bytes),

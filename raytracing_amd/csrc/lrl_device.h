@@ -120,7 +120,10 @@ enum { LRL_CTR_PRIMARY = 0, LRL_CTR_REFLECT, LRL_CTR_REFRACT, LRL_CTR_SHADOW, LR
 #endif
 #ifndef LRL_SWARM_CAP
 #define LRL_SWARM_CAP 1024         /* frontier entries of the wave-per-ray continuation kernel (LDS) */
-#define LRL_WORK_COUNTERS 4u
+#endif
+#define LRL_WORK_COUNTERS 4u         /* per iteration, 128 B apart: sampled work of the hand-over kernels (feedback) */
+#ifndef LRL_GROUP_CAP
+#define LRL_GROUP_CAP 256u           /* frontier entries of one ray in the lanes-per-ray kernel (tests build it smaller) */
 #endif
 #define LRL_WF_SLOT_ALIGN (64u * LRL_WF_CHUNK_WORDS > 256u ? 64u * LRL_WF_CHUNK_WORDS : 256u)
 
@@ -155,9 +158,6 @@ struct WFrame {
     // its pending work here and a whole wave finishes it
     uint32_t* contWork;      // LRL_WORK_COUNTERS counters, 128 B apart: frontier entries the hand-over kernel tested in this iteration
     uint32_t handoverTrips;  // 0: never hand over
-    uint32_t handoverStep;   // trips between the checks after the first
-    uint32_t handoverRefs;   // at the first check only the rays with at least this many pending refs leave (the others are nearly done)
-    uint32_t handoverLanes;  // a wave hands its rays over only when at most this many lanes are still going
     uint32_t contSlots;      // capacity of contHead / contRefs
     uint32_t contStride;     // refs per slot (>= deepest stack + 1)
     uint32_t* contCount;     // slots taken by this launch (zero before it)

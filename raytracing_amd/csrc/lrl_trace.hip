@@ -801,7 +801,7 @@ static int renderWavefront(LrlContext* c, const LrlRenderParams* p, const KScene
     const char* groupEnv = std::getenv("LRL_SWARM_GROUP");
     uint32_t swarmGroup = groupEnv ? uint32_t(std::atoi(groupEnv)) : 16u;
     if (swarmGroup != 8 && swarmGroup != 16 && swarmGroup != 32) swarmGroup = 64;
-    if (swarmGroup != 64 && 2 * contStride + 3 * swarmGroup > 256) swarmGroup = 64;
+    if (swarmGroup != 64 && 2 * contStride + 3 * swarmGroup > LRL_GROUP_CAP) swarmGroup = 64;
     const char* sparseEnv = std::getenv("LRL_SPARSE_FROM");      // first iteration traced with the larger workgroups
     const uint32_t sparseFrom = sparseEnv ? uint32_t(std::atoi(sparseEnv)) : 5u;      // (measured: C2 best with none of its 5, C1 with 8 of its 56, C3 with 4 of its 10)
     const bool adapt = !(std::getenv("LRL_ADAPT") && std::atoi(std::getenv("LRL_ADAPT")) == 0);
@@ -840,12 +840,6 @@ static int renderWavefront(LrlContext* c, const LrlRenderParams* p, const KScene
         c->contIters = 0;
     };
     wf.handoverTrips = handoverEarly;
-    const char* lanesEnv = std::getenv("LRL_HANDOVER_LANES");
-    const char* stepEnv = std::getenv("LRL_HANDOVER_STEP");
-    const char* refsEnv = std::getenv("LRL_HANDOVER_REFS");
-    wf.handoverRefs = refsEnv ? uint32_t(std::atoi(refsEnv)) : 1u;
-    wf.handoverLanes = lanesEnv ? uint32_t(std::atoi(lanesEnv)) : 64u;
-    wf.handoverStep = stepEnv ? std::max(1u, uint32_t(std::atoi(stepEnv))) : 8u;
     wf.contSlots = contSlots; wf.contStride = contStride;
     wf.contHead = reinterpret_cast<uint4*>(base + oContHead);
     wf.contRefs = reinterpret_cast<uint32_t*>(base + oContRefs);
@@ -900,8 +894,9 @@ static int renderWavefront(LrlContext* c, const LrlRenderParams* p, const KScene
     for (uint32_t s = f.sampleBegin; s < f.sampleEnd; ++s) {
         wf.sample = s;
         if (special) feedback();
-        HIP_TRY(c, hipMemsetAsync(wf.alive, 0, size_t(LRL_WF_MAX_ITERATIONS) * 4 + size_t(bound) * 4, stream));
-        if (special) HIP_TRY(c, hipMemsetAsync(contWorkAll, 0, size_t(std::min(bound, LRL_FEEDBACK_ITERS)) * LRL_WORK_COUNTERS * 128, stream));
+        // one fill (a size that is no multiple of 16 B costs a second fill kernel): alive, hand-over counts, work counters
+        HIP_TRY(c, hipMemsetAsync(wf.alive, 0, special ? size_t(LRL_WF_MAX_ITERATIONS) * 8 + size_t(LRL_FEEDBACK_ITERS) * LRL_WORK_COUNTERS * 128
+                                                       : size_t(LRL_WF_MAX_ITERATIONS) * 4, stream));
         HIP_TRY(c, fast ? lrl_fast::wfLaunchGenerate(k, f, wf, stream) : lrl_parity::wfLaunchGenerate(k, f, wf, stream));
         uint32_t iter = 0;
         for (; iter < bound; ++iter) {
@@ -935,7 +930,7 @@ static int renderWavefront(LrlContext* c, const LrlRenderParams* p, const KScene
             HIP_TRY(c, hipMemcpy(cc.data(), contCounts, iter * 4, hipMemcpyDeviceToHost));
             std::fprintf(stderr, "lrl: handed-over rays per iteration (threshold, entries per ray at the last feedback):");
             for (uint32_t i = 0; i < iter; ++i) std::fprintf(stderr, " %u (%u, %.0f)", cc[i], c->handoverThr[std::min(i, LRL_FEEDBACK_ITERS - 1)], c->workPerRay[std::min(i, LRL_FEEDBACK_ITERS - 1)]);
-            std::fprintf(stderr, "\n");
+            std::fprintf(stderr, "  [%u lanes per handed-over ray, stride %u]\n", swarmGroup, contStride);
         }
     }
     if (e1) HIP_TRY(c, hipEventRecord(e1, stream));

@@ -302,6 +302,41 @@ def test_headline_workload_properties(tracer):
     assert image_stats(base_img[r0:r0 + 16], oimg)["rmse"] <= RMSE_PARITY
 
 
+def test_hand_over_kernels_agree(default_model, bunny0_model):
+    """FAST mode's continuation kernels (16 lanes per ray, and one wave per ray for deep trees) keep no visit order; the
+    closest hit must come out all the same.  With a threshold of 4 trips nearly every ray goes through them: both must
+    agree with each other and with the default schedule (ties between coincident primitives aside, as in the FAST bars)."""
+    from raytracing_amd import tracer as T
+    knobs = ("LRL_ADAPT", "LRL_HANDOVER_LIST", "LRL_SWARM_GROUP")
+    saved = {k: os.environ.get(k) for k in knobs}
+    t = T.Tracer(0)
+    try:
+        for m, (W, H) in ((default_model, (256, 256)), (bunny0_model, (640, 360))):
+            tr = m.camera(H)
+            res = {}
+            for group in (None, "64", "16"):
+                for k in knobs:
+                    os.environ.pop(k, None)
+                if group:
+                    os.environ.update(LRL_ADAPT="0", LRL_HANDOVER_LIST="4", LRL_SWARM_GROUP=group)
+                t.scene_upload(m.scene_view())              # the thresholds start again with a scene
+                t.set_camera(tr, W, H)
+                t.set_decay_origin((0, 0, 0, 1))
+                res[group] = t.render(max_depth=4, mode=abi.MODE_FAST)
+            for group in ("64", "16"):
+                assert (res[group][1] == res[None][1]).all(axis=-1).mean() >= 0.9995, group
+                assert image_stats(res[group][0], res[None][0])["rmse"] <= RMSE_FAST, group
+            assert (res["64"][1] == res["16"][1]).all(axis=-1).mean() >= ID_BAR
+            assert image_stats(res["64"][0], res["16"][0])["rmse"] <= RMSE_FAST
+    finally:
+        t.close()
+        for k, v in saved.items():
+            if v is None:
+                os.environ.pop(k, None)
+            else:
+                os.environ[k] = v
+
+
 @pytest.mark.parametrize("name", ["bvh_viewB_256", "bvh_viewB_128_spp4", "bvh_inside_glass_128"])
 def test_wavefront_and_megakernel_schedules_agree_bit_for_bit(tracer, default_model, name):
     """The wavefront pipeline (default) and the one-launch kernel run the same PARITY arithmetic in a different order of

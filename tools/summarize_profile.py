@@ -7,7 +7,7 @@ HBM traffic per frame follows /opt/skills/guides/MI355X_MICROARCH.md: FETCH_SIZE
 FETCH_SIZE tallies the 128-B requests of 16-B-per-lane loads at 64 B, so it is doubled; WRITE_SIZE is exact."""
 import collections, csv, glob, json, shutil, sys
 tag, stats_dir, note = sys.argv[1], sys.argv[2], sys.argv[3]
-frames = int(sys.argv[4]) if len(sys.argv) > 4 else 5          # run_pmc.sh: --steps 4 --warmup 1
+frames = int(sys.argv[4]) if len(sys.argv) > 4 else 10         # run_pmc.sh: --steps 4 --warmup 1, and bench.py renders 5 more for its per-kernel timing
 shutil.copyfile(glob.glob(f"gpurun_out/{stats_dir}/*kernel_stats.csv")[0], f"profiles/{tag}_kernel_stats.csv")
 per = collections.defaultdict(lambda: collections.defaultdict(float))
 meta = {}
