@@ -53,6 +53,7 @@ def main():
                          "RayTraceDepth 10 | c3: Pool demo scene, Pool shader variant, 64 spp (SURVEY 8d)")
     ap.add_argument("--grid", type=int, default=1, help="c2 only: grid x grid replicated copies of the mesh (towards C5: 9 -> 100.5 M triangles)")
     ap.add_argument("--spp", type=int, default=0, help="samples per pixel (0 = the workload's own: 1 for c2, 64 for c3)")
+    ap.add_argument("--diffuse", action="store_true", help="LRL_FLAG_DIFFUSE_BOUNCE: cosine-weighted continuation rays (SURVEY 8d C5: incoherent secondary rays)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-rows", type=int, default=0, help="rows of the frame the CPU baseline renders (0 = auto)")
     a = ap.parse_args()
@@ -121,7 +122,7 @@ def main():
     samples = (rank * a.spp, (rank + 1) * a.spp) if world > 1 else None
 
     # ---- ray / node / primitive-test counts of this rank's frame (counting variant, un-timed) ----
-    _, _ = tr.render(max_depth=a.depth, variant=variant, mode=mode, counters=True, jitter=jitter, samples=samples, want_hits=False)
+    _, _ = tr.render(max_depth=a.depth, variant=variant, mode=mode, counters=True, jitter=jitter, samples=samples, want_hits=False, diffuse=a.diffuse)
     cn = tr.counters()
     rays, alg_bytes = cn.rays, cn.algorithmic_bytes()
 
@@ -136,7 +137,7 @@ def main():
 
     def step():
         if world == 1:
-            tr.render_device(out.data_ptr(), max_depth=a.depth, variant=variant, mode=mode, jitter=jitter, samples=samples)
+            tr.render_device(out.data_ptr(), max_depth=a.depth, variant=variant, mode=mode, jitter=jitter, samples=samples, diffuse=a.diffuse)
             return
         b = counter[0] & 1
         counter[0] += 1
@@ -145,7 +146,7 @@ def main():
             # all-reduce of frame i - 1 runs; then that one is waited for (RCCL: a wait of the render stream, not of the
             # host) and the all-reduce of frame i is queued behind its render: never more than one collective in flight
             tr.render_device(outs[b].data_ptr(), stream=render_stream.cuda_stream, max_depth=a.depth, variant=variant, mode=mode,
-                             jitter=jitter, samples=samples)
+                             jitter=jitter, samples=samples, diffuse=a.diffuse)
             if works[1 - b] is not None:
                 works[1 - b].wait()
                 works[1 - b] = None
@@ -180,7 +181,7 @@ def main():
     TRACE_FRAMES = 5
     tr.timing_begin()
     for _ in range(TRACE_FRAMES):
-        tr.render_device(out.data_ptr(), max_depth=a.depth, variant=variant, mode=mode, jitter=jitter, samples=samples, time_kernels=True)
+        tr.render_device(out.data_ptr(), max_depth=a.depth, variant=variant, mode=mode, jitter=jitter, samples=samples, time_kernels=True, diffuse=a.diffuse)
     tr.sync()
     trace_ms_total, trace_launches = tr.timing_end()
 
@@ -204,7 +205,7 @@ def main():
         tpath = os.path.join(REPO, "profiles", "r01_traffic.json")        # PMC passes are separate runs (tools/run_pmc.sh)
         if os.path.exists(tpath):
             tj = json.load(open(tpath))
-            if tj.get("workload_triangles") == int(view.num.triangleNum) and tj.get("mode") == a.mode and tj.get("builder") == a.builder:
+            if tj.get("workload_triangles") == int(view.num.triangleNum) and tj.get("mode") == a.mode and tj.get("builder") == a.builder and not a.diffuse:
                 traffic = tj.get("hbm_bytes_per_frame")
         dbytes = tr.scene_device_bytes()
         line = {
@@ -214,7 +215,7 @@ def main():
             "config": {"workload": (f"C1: the reference's default BVH scene ({view.num.triangleNum} triangles + spheres, discs, cylinders, cones), " if c1 else
                                     f"C3: Pool demo scene ({view.num.triangleNum} triangles, water at rest), Pool shader variant, " if c3 else
                                     f"C2: Stanford bunny x{a.subdivisions} subdivisions{f', {a.grid}x{a.grid} copies' if a.grid > 1 else ''} ({view.num.triangleNum} triangles) + ground disc + 1 light, ") +
-                                   f"{W}x{H}, {a.spp} spp per GPU, RayTraceDepth {a.depth}",
+                                   f"{W}x{H}, {a.spp} spp per GPU, RayTraceDepth {a.depth}" + (", diffuse bounces (Philox, cosine-weighted)" if a.diffuse else ""),
                        "bvh_builder": a.builder, "bvh_nodes": info["nodes"], "bvh_depth": info["max_depth"], "arithmetic": a.mode,
                        "parallelism": f"replicated scene, {a.spp} sample indices per GPU, RCCL all-reduce of the image" if world > 1 else "1 GPU",
                        "rays_per_frame": int(rays), "host_scene_build_s": round(build_s, 2), "scene_upload_s": round(upload_s, 2),
@@ -247,7 +248,7 @@ def cpu_baseline(a, m, view, trans, W, H, variant):
     rays, dt, reps = 0, 0.0, 0
     while dt < 12.0 or reps < 2:
         t0 = time.perf_counter()
-        _, _, c = O.render(view, trans, W, H, max_depth=a.depth, variant=variant, rows=(r0, r0 + rows), threads=cores, want_hits=False)
+        _, _, c = O.render(view, trans, W, H, max_depth=a.depth, variant=variant, rows=(r0, r0 + rows), threads=cores, want_hits=False, diffuse=a.diffuse)
         dt += time.perf_counter() - t0
         rays += c.rays
         reps += 1

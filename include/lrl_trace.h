@@ -70,6 +70,14 @@ enum LrlStatus {
                                   /* trace + one shade launch per ray segment                                        */
 #define LRL_FLAG_TIME_KERNELS 8u  /* between lrl_timing_begin/_end: time every trace-kernel launch on its own instead */
                                   /* of the frame as a whole (adds event records between the launches)               */
+#define LRL_FLAG_DIFFUSE_BOUNCE 16u /* SURVEY 8d, C5 (no counterpart in the reference's shader, whose a11 step            */
+                                  /* `RendererFragment0.cpp:718-740` always mirrors): the ray that continues after a   */
+                                  /* hit takes a cosine-weighted direction about the normal on the incoming side, so    */
+                                  /* that secondary rays are incoherent.  Philox4x32-10, counter (pixel = y*width + x,  */
+                                  /* sample, depth of the segment that hit, 0), key (0, 0): u1, u2 = top 24 bits;       */
+                                  /* dir = sqrt(u1)(cos(2 pi u2) T + sin(2 pi u2) B) + sqrt(1-u1) N.  Everything else   */
+                                  /* (materials, lights, refraction, `ratioNow *= r`) is unchanged.  Not with           */
+                                  /* LRL_FLAG_MEGAKERNEL.  Oracle: oracle_render with OracleParams.diffuse.             */
 
 typedef struct LrlSceneView {
     /* geometry in the reference's record layouts; counts in `num` */

@@ -28,11 +28,11 @@ def lib():
 
 
 def render(view, trans, width, height, max_depth=10, variant=abi.VARIANT_BVH, decay_origin=(0, 0, 0, 1), rows=None, threads=1,
-           want_hits=True):
-    """-> (rgba [rows, W, 4] float32, hits [rows, W, 2] uint32 or None, abi.Counters)"""
+           want_hits=True, diffuse=False):
+    """-> (rgba [rows, W, 4] float32, hits [rows, W, 2] uint32 or None, abi.Counters); diffuse: LRL_FLAG_DIFFUSE_BOUNCE"""
     trans = np.ascontiguousarray(trans, dtype=abi.TRANS).reshape(-1)
     r0, r1 = rows if rows else (0, height)
-    p = abi.OracleParams(width, height, max_depth, variant, trans.shape[0], r0, r1, threads, (C.c_float * 4)(*decay_origin))
+    p = abi.OracleParams(width, height, max_depth, variant, trans.shape[0], r0, r1, threads, (C.c_float * 4)(*decay_origin), 1 if diffuse else 0)
     img = np.zeros((r1 - r0, width, 4), dtype=np.float32)
     hits = np.zeros((r1 - r0, width, 2), dtype=np.uint32) if want_hits else None
     cn = abi.Counters()
@@ -41,6 +41,20 @@ def render(view, trans, width, height, max_depth=10, variant=abi.VARIANT_BVH, de
     if rc != 0:
         raise RuntimeError(f"oracle_render failed ({rc})")
     return img, hits, cn
+
+
+def philox4x32_10(counter):
+    ctr = (C.c_uint32 * 4)(*counter)
+    out = (C.c_uint32 * 4)()
+    lib().oracle_philox4x32_10(ctr, out)
+    return tuple(out)
+
+
+def diffuse_direction(normal, cosi1, pixel, sample, depth):
+    n = (C.c_float * 3)(*normal)
+    out = (C.c_float * 3)()
+    lib().oracle_diffuse_direction(n, C.c_float(cosi1), C.c_uint32(pixel), C.c_uint32(sample), C.c_uint32(depth), out)
+    return np.array(out, dtype=np.float32)
 
 
 def triangle_pre(tris):

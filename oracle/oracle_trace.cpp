@@ -73,6 +73,8 @@ struct Scene {
     uint32_t cubeSize = 0; const uint8_t* cube[6] = {};
     uint32_t variant = 0, maxDepth = 10;
     float decayOrigin[4] = {0, 0, 0, 1};
+    bool diffuse = false;       // include/lrl_trace.h LRL_FLAG_DIFFUSE_BOUNCE (not in the reference's shader)
+    uint32_t width = 0;         // of the full frame, for the pixel index of the random stream
 };
 
 struct Counters { uint64_t primary = 0, reflect = 0, refract = 0, shadow = 0, nodes = 0, tri = 0, sph = 0, other = 0, primaryHits = 0; };
@@ -520,7 +522,46 @@ inline float checker(float u, float v) { return float((uint32_t(20 * u) + uint32
 struct StackEntry { V3 p0; V3 n; int depth; V3 ratio; V3 decay; };
 
 // ---- rayTrace (:393-741) ----
-V3 rayTrace(const Scene& sc, Ray ray, Counters& cn, uint32_t* primaryHit) {
+// ---- diffuse bounce as include/lrl_trace.h defines it (LRL_FLAG_DIFFUSE_BOUNCE): the library's own extension for
+// SURVEY 8d's C5, restated here independently of the device code ----
+static void philox4x32_10(const uint32_t ctr[4], uint32_t out[4]) {
+    uint32_t c[4] = {ctr[0], ctr[1], ctr[2], ctr[3]}, key[2] = {0u, 0u};
+    for (int round = 0; round < 10; ++round) {
+        uint64_t a = uint64_t(0xD2511F53u) * c[0], b = uint64_t(0xCD9E8D57u) * c[2];
+        uint32_t n[4] = {uint32_t(b >> 32) ^ c[1] ^ key[0], uint32_t(b), uint32_t(a >> 32) ^ c[3] ^ key[1], uint32_t(a)};
+        std::memcpy(c, n, sizeof n);
+        key[0] += 0x9E3779B9u; key[1] += 0xBB67AE85u;
+    }
+    std::memcpy(out, c, sizeof c);
+}
+static float sinQuarterTurn(float x) {      // sin(pi/2 x) on [0, 1], the polynomial the definition names
+    float x2 = x * x;
+    return x * (1.57079632679f + x2 * (-0.64596409750f + x2 * (0.07969262624f + x2 * (-0.00468175413f + x2 * 0.00016044118f))));
+}
+static V3 diffuseDirection(V3 N, float cosi1, uint32_t pixel, uint32_t sample, uint32_t depth) {
+    uint32_t ctr[4] = {pixel, sample, depth, 0u}, r[4];
+    philox4x32_10(ctr, r);
+    float u1 = float(r[0] >> 8) * (1.0f / 16777216.0f), u2 = float(r[1] >> 8) * (1.0f / 16777216.0f);
+    float q = u2 * 4.0f;
+    int quad = int(q);
+    float f = q - float(quad);
+    float sq = sinQuarterTurn(f), cq = sinQuarterTurn(1.0f - f), c, s;
+    switch (quad) {
+        case 0: c = cq; s = sq; break;
+        case 1: c = -sq; s = cq; break;
+        case 2: c = -cq; s = -sq; break;
+        default: c = sq; s = -cq; break;
+    }
+    V3 n = cosi1 > 0 ? V3{-N.x, -N.y, -N.z} : N;
+    float sg = n.z >= 0 ? 1.0f : -1.0f;
+    float a = -1.0f / (sg + n.z), b = (n.x * n.y) * a;
+    V3 T = {1.0f + (sg * (n.x * n.x)) * a, sg * b, -(sg * n.x)};
+    V3 B = {b, sg + (n.y * n.y) * a, -n.y};
+    float rr = std::sqrt(u1), h = std::sqrt(1.0f - u1);
+    return normalize(((rr * c) * T + (rr * s) * B) + h * n);
+}
+
+V3 rayTrace(const Scene& sc, Ray ray, Counters& cn, uint32_t* primaryHit, uint32_t rngPixel = 0, uint32_t rngSample = 0) {
     StackEntry stack[LRL_MAX_RAY_DEPTH];
     int sp = -1, depth = 0;
     const int maxDepth = int(sc.maxDepth);
@@ -602,7 +643,8 @@ V3 rayTrace(const Scene& sc, Ray ray, Counters& cn, uint32_t* primaryHit) {
             if (col.texR >= 0) r = r * texture2DArray(sc, hit.u, hit.v, col.texR);
             ratioNow = ratioNow * r;
             if (anyGE(ratioNow, kMinColor)) {
-                ray.n = ray.n - (2 * cosi1) * hit.n;
+                if (sc.diffuse) ray.n = diffuseDirection(hit.n, cosi1, rngPixel, rngSample, uint32_t(depth));
+                else ray.n = ray.n - (2 * cosi1) * hit.n;
                 ++depth;
                 ++cn.reflect;
                 continue;
@@ -650,7 +692,15 @@ extern "C" {
 struct OracleParams {
     uint32_t width, height, maxDepth, variant, nSamples, rowBegin, rowEnd, threads;
     float decayOrigin[4];
+    uint32_t diffuse;        // LRL_FLAG_DIFFUSE_BOUNCE semantics
 };
+
+// the two pieces of the diffuse bounce, for known-answer tests
+void oracle_philox4x32_10(const uint32_t ctr[4], uint32_t out[4]) { philox4x32_10(ctr, out); }
+void oracle_diffuse_direction(const float N[3], float cosi1, uint32_t pixel, uint32_t sample, uint32_t depth, float out[3]) {
+    V3 d = diffuseDirection(V3{N[0], N[1], N[2]}, cosi1, pixel, sample, depth);
+    out[0] = d.x; out[1] = d.y; out[2] = d.z;
+}
 
 int oracle_triangle_pre(const LrlTriangle* in, uint32_t n, LrlTriangleGPU* out) {
     for (uint32_t i = 0; i < n; ++i) trianglePre(in[i], out[i]);
@@ -668,6 +718,7 @@ int oracle_render(const LrlSceneView* sv, const LrlTrans* trans, const OraclePar
     buildScene(sv, sc);
     sc.variant = p->variant; sc.maxDepth = p->maxDepth;
     std::memcpy(sc.decayOrigin, p->decayOrigin, 16);
+    sc.diffuse = p->diffuse != 0; sc.width = p->width;
     uint32_t r0 = p->rowBegin, r1 = p->rowEnd ? p->rowEnd : p->height;
     Counters total;
     int threads = p->threads ? int(p->threads) : 1;
@@ -685,7 +736,7 @@ int oracle_render(const LrlSceneView* sv, const LrlTrans* trans, const OraclePar
                 size_t o = (size_t(y - r0) * p->width + x);
                 for (uint32_t s = 0; s < p->nSamples; ++s) {
                     Ray ray = primaryRay(trans[s], p->width, p->height, x, uint32_t(y));
-                    V3 c = rayTrace(sc, ray, cn, (hit && s == 0) ? hit + o * 2 : nullptr);
+                    V3 c = rayTrace(sc, ray, cn, (hit && s == 0) ? hit + o * 2 : nullptr, uint32_t(y) * p->width + x, s);
                     acc = p->nSamples == 1 ? c : acc + c;
                 }
                 if (p->nSamples > 1) acc = acc / float(p->nSamples);

@@ -31,7 +31,7 @@ for _dt, _sz in ((COLOR, 80), (BVHNODE, 64), (TRIANGLE, 160), (TRIANGLE_GPU, 176
 GEOM_TRIANGLE, GEOM_SPHERE, GEOM_CIRCLE, GEOM_CYLINDER, GEOM_CONE = 2, 3, 4, 5, 6
 VARIANT_BVH, VARIANT_POOL = 0, 1
 MODE_PARITY, MODE_FAST = 0, 1
-FLAG_COUNTERS, FLAG_OUT_DEVICE, FLAG_MEGAKERNEL, FLAG_TIME_KERNELS = 1, 2, 4, 8
+FLAG_COUNTERS, FLAG_OUT_DEVICE, FLAG_MEGAKERNEL, FLAG_TIME_KERNELS, FLAG_DIFFUSE_BOUNCE = 1, 2, 4, 8, 16
 
 
 def color(r=0.0, t=0.0, d=0.0, g=0.0, decay=0.0, n=1.0, texR=-1, texT=-1, texD=-1, texG=-1):
@@ -80,7 +80,7 @@ class Counters(C.Structure):
 class OracleParams(C.Structure):
     _fields_ = [("width", C.c_uint32), ("height", C.c_uint32), ("maxDepth", C.c_uint32), ("variant", C.c_uint32),
                 ("nSamples", C.c_uint32), ("rowBegin", C.c_uint32), ("rowEnd", C.c_uint32), ("threads", C.c_uint32),
-                ("decayOrigin", C.c_float * 4)]
+                ("decayOrigin", C.c_float * 4), ("diffuse", C.c_uint32)]
 
 
 def scene_view_arrays(view):

@@ -78,6 +78,7 @@ struct KFrame {
     uint32_t spp;                      // divisor of the mean
     uint32_t maxDepth;
     uint32_t stackEntries;             // LDS traversal-stack entries per lane: min(BVH depth + 1, LRL_LDS_STACK_ENTRIES)
+    uint32_t diffuse;                  // LRL_FLAG_DIFFUSE_BOUNCE: cosine-weighted continuation instead of the mirror direction (wavefront pipeline)
     unsigned long long* timeline;      // diagnostic (env LRL_TIMELINE): per wave {start, end} in 100 MHz ticks + hardware id, else NULL
 };
 

@@ -980,6 +980,8 @@ static int renderImpl(LrlContext* c, const LrlRenderParams* p, float* rgbaDev, u
     f.maxDepth = p->maxDepth;
     f.stackEntries = std::min(c->bvhDepth + 1, LRL_LDS_STACK_ENTRIES);
     f.timeline = nullptr;
+    f.diffuse = (p->flags & LRL_FLAG_DIFFUSE_BOUNCE) ? 1u : 0u;
+    if (f.diffuse && (p->flags & LRL_FLAG_MEGAKERNEL)) return fail(c, LRL_ERR_INVALID_ARG, "LRL_FLAG_DIFFUSE_BOUNCE is implemented in the wavefront pipeline only");
     const char* tlPath = std::getenv("LRL_TIMELINE");   // diagnostic: per-wave start/end ticks of this launch, dumped to the named file
     size_t tlWaves = 0;
     if (tlPath && *tlPath) {

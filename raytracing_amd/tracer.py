@@ -156,9 +156,10 @@ class Tracer:
         return abi.RenderParams(max_depth, variant, mode, flags, spp, jp, r0, r1, s0, s1)
 
     def render(self, max_depth=10, variant=abi.VARIANT_BVH, mode=abi.MODE_PARITY, counters=False, jitter=None, rows=None,
-               samples=None, want_hits=True, megakernel=False):
-        """-> (rgba [rows, W, 4] float32, hits [rows, W, 2] uint32 or None).  megakernel=True: the one-launch schedule."""
-        flags = (abi.FLAG_COUNTERS if counters else 0) | (abi.FLAG_MEGAKERNEL if megakernel else 0)
+               samples=None, want_hits=True, megakernel=False, diffuse=False):
+        """-> (rgba [rows, W, 4] float32, hits [rows, W, 2] uint32 or None).  megakernel=True: the one-launch schedule;
+        diffuse=True: LRL_FLAG_DIFFUSE_BOUNCE (cosine-weighted continuation rays)."""
+        flags = (abi.FLAG_COUNTERS if counters else 0) | (abi.FLAG_MEGAKERNEL if megakernel else 0) | (abi.FLAG_DIFFUSE_BOUNCE if diffuse else 0)
         p = self._params(max_depth, variant, mode, flags, jitter, rows, samples)
         nrows = (rows[1] - rows[0]) if rows else self.height
         img = np.zeros((nrows, self.width, 4), dtype=np.float32)
@@ -168,9 +169,10 @@ class Tracer:
         return img, hits
 
     def render_device(self, out_ptr, hit_ptr=None, stream=None, max_depth=10, variant=abi.VARIANT_BVH, mode=abi.MODE_PARITY,
-                      jitter=None, rows=None, samples=None, megakernel=False, time_kernels=False):
+                      jitter=None, rows=None, samples=None, megakernel=False, time_kernels=False, diffuse=False):
         """Render into device memory (e.g. torch tensors' data_ptr()) on `stream` (a raw hipStream_t or None), without a final sync."""
-        flags = abi.FLAG_OUT_DEVICE | (abi.FLAG_MEGAKERNEL if megakernel else 0) | (abi.FLAG_TIME_KERNELS if time_kernels else 0)
+        flags = (abi.FLAG_OUT_DEVICE | (abi.FLAG_MEGAKERNEL if megakernel else 0) | (abi.FLAG_TIME_KERNELS if time_kernels else 0)
+                 | (abi.FLAG_DIFFUSE_BOUNCE if diffuse else 0))
         p = self._params(max_depth, variant, mode, flags, jitter, rows, samples)
         self._ck(self._L.lrl_render_async(self._ctx, C.byref(p), C.c_void_p(out_ptr), C.c_void_p(hit_ptr) if hit_ptr else None,
                                           C.c_void_p(stream) if stream else None))

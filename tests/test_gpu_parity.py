@@ -302,6 +302,36 @@ def test_headline_workload_properties(tracer):
     assert image_stats(base_img[r0:r0 + 16], oimg)["rmse"] <= RMSE_PARITY
 
 
+def test_diffuse_bounce_vs_oracle(tracer, default_model, bunny0_model):
+    """LRL_FLAG_DIFFUSE_BOUNCE (incoherent secondary rays; no reference counterpart, so the oracle's own
+    restatement is the truth, pinned on the CPU by Philox's known answer and the sampler's distribution).  PARITY computes
+    the same directions bit for bit, so image and ray counts meet the bars of the mirror mode; FAST contracts
+    multiply-adds, so a direction may move by an ulp and a bounce near an edge may land elsewhere: image bar only."""
+    for m, (W, H), depth in ((default_model, (96, 96), 4), (bunny0_model, (160, 90), 4)):
+        tr = m.camera(H)
+        view = m.scene_view()
+        tracer.scene_upload(view)
+        tracer.set_camera(tr, W, H)
+        tracer.set_decay_origin((0, 0, 0, 1))
+        oimg, ohits, oc = O.render(view, tr, W, H, max_depth=depth, threads=8, diffuse=True)
+        img, hits = tracer.render(max_depth=depth, mode=abi.MODE_PARITY, counters=True, diffuse=True)
+        c = tracer.counters()
+        assert (hits == ohits).all(axis=-1).mean() >= ID_BAR
+        st = image_stats(img, oimg)
+        assert st["rmse"] <= RMSE_PARITY and st["frac_gt_1e-3"] <= 2e-3, st
+        assert abs(c.rays - oc.rays) <= 2e-3 * oc.rays and c.raysPrimary == oc.raysPrimary
+        mirror, _ = tracer.render(max_depth=depth, mode=abi.MODE_PARITY)
+        assert not np.array_equal(mirror, img)
+        fast, fhits = tracer.render(max_depth=depth, mode=abi.MODE_FAST, diffuse=True)
+        assert (fhits == ohits).all(axis=-1).mean() >= ID_BAR
+        assert image_stats(fast, oimg)["rmse"] <= 4 * RMSE_FAST
+        # stripes and sample ranges compose (the stream is keyed by pixel and sample of the full frame)
+        stripe, _ = tracer.render(max_depth=depth, mode=abi.MODE_PARITY, rows=(32, 48), diffuse=True)
+        assert np.array_equal(stripe, img[32:48])
+    with pytest.raises(Exception):
+        tracer.render(max_depth=4, diffuse=True, megakernel=True)
+
+
 def test_hand_over_kernels_agree(default_model, bunny0_model):
     """FAST mode's continuation kernels (16 lanes per ray, and one wave per ray for deep trees) keep no visit order; the
     closest hit must come out all the same.  With a threshold of 4 trips nearly every ray goes through them: both must
