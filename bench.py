@@ -178,7 +178,8 @@ def main():
     frame_ms_total, frames = tr.timing_end()
 
     # ---- trace-kernel time of one frame (HIP events around every trace launch), separate short pass ----
-    TRACE_FRAMES = 5
+    # (the library keeps at most 4096 timed launches: one frame is enough where a frame has hundreds of them)
+    TRACE_FRAMES = 5 if a.spp <= 64 else 1
     tr.timing_begin()
     for _ in range(TRACE_FRAMES):
         tr.render_device(out.data_ptr(), max_depth=a.depth, variant=variant, mode=mode, jitter=jitter, samples=samples, time_kernels=True, diffuse=a.diffuse)
@@ -200,12 +201,15 @@ def main():
         value = rays_all * a.steps / elapsed / 1e6
         frame_ms = frame_ms_total / max(frames, 1)
         kernel_ms = trace_ms_total / TRACE_FRAMES
+        if trace_launches >= 4096:
+            raise SystemExit("bench.py: more trace launches per timed pass than the library keeps events for; lower --spp")
         achieved = alg_bytes / (kernel_ms * 1e-3) / 1e9
         traffic = None
         tpath = os.path.join(REPO, "profiles", "r01_traffic.json")        # PMC passes are separate runs (tools/run_pmc.sh)
         if os.path.exists(tpath):
             tj = json.load(open(tpath))
-            if tj.get("workload_triangles") == int(view.num.triangleNum) and tj.get("mode") == a.mode and tj.get("builder") == a.builder and not a.diffuse:
+            if (tj.get("workload_triangles") == int(view.num.triangleNum) and tj.get("mode") == a.mode and tj.get("builder") == a.builder
+                    and not a.diffuse and (W, H, a.spp, a.depth) == (1920, 1080, 1, 4)):      # what the PMC passes ran
                 traffic = tj.get("hbm_bytes_per_frame")
         dbytes = tr.scene_device_bytes()
         line = {
