@@ -155,6 +155,7 @@ struct WFrame {
     float4* refr;            // refraction stack [entry][4][P], NULL when no material transmits
     uint2* overflow;         // [trace workgroup][overflowEntries][64]
     uint32_t* alive;         // [iteration]: set to 1 by the shade kernel while any path is unfinished
+    uint32_t* aliveHost;     // the same words in pinned host memory when the host polls them (scenes with transmission), else NULL
     // hand-over of long chains (lrl_lean.inc -> wfTraceSwarmKernel): a ray still going after `handoverTrips` trips leaves
     // its pending work here and a whole wave finishes it
     uint32_t* contWork;      // LRL_WORK_COUNTERS counters, 128 B apart: frontier entries the hand-over kernel tested in this iteration

@@ -63,17 +63,19 @@ struct LrlContext {
     uint32_t node4Depth = 0;   // depth of the four-wide tree (nodes32)
     DevBuf transDev, outDev, hitDev, counterDev, decayDev, timelineDev;
     DevBuf wfArena;                     // wavefront pipeline: path state, ray records, masks, refraction stacks, overflow stacks
-    uint32_t* aliveHost = nullptr;      // pinned: per-iteration "any path alive" words copied back while the next iteration runs
+    uint32_t* aliveHost = nullptr;      // pinned, 2 x LRL_WF_MAX_ITERATIONS (alternating by sample): per-iteration "any path alive" words the shade kernel writes
+    uint32_t* aliveHostDev = nullptr;   // the device's address of the same memory
     // feedback for the hand-over thresholds of the FAST trace kernels: rays handed over per iteration of the last finished
     // sample (pinned copy, read when its event has completed: never waited for)
     uint32_t* contHost = nullptr;
     hipEvent_t evCont = nullptr;
     std::vector<float> workPerRay;      // per iteration: frontier entries per handed-over ray, last feedback
+    uint32_t feedbackTick = 0;          // samples rendered since the thresholds were reset
     uint32_t contIters = 0;             // words of contHost in flight / ready
     std::vector<LrlTrans> transUploaded;   // what transDev holds (per-sample cameras of the last render)
     std::vector<uint32_t> handoverThr;  // per iteration index; empty until first use
     std::vector<uint32_t> swarmGrid;    // waves launched for the handed-over rays of that iteration (a grid-stride kernel)
-    hipEvent_t evIter[2] = {nullptr, nullptr};
+    hipEvent_t evIter[4] = {nullptr, nullptr, nullptr, nullptr};
     bool hasTransmission = false;       // some material has t != 0: refraction stacks are needed
     uint32_t lastIterations = 0;
     float lastMs = 0;
@@ -484,7 +486,7 @@ int lrl_destroy(LrlContext* c) {
 }
 
 int lrl_scene_upload(LrlContext* c, const LrlSceneView* s) {
-    if (c) c->handoverThr.clear();       // the hand-over thresholds start again with a new scene
+    if (c) { c->handoverThr.clear(); c->feedbackTick = 0; }      // the hand-over thresholds start again with a new scene
     if (!c || !s) return LRL_ERR_INVALID_ARG;
     HIP_TRY(c, hipSetDevice(c->device));
     const LrlGeometryNum& g = s->num;
@@ -766,9 +768,9 @@ static int renderWavefront(LrlContext* c, const LrlRenderParams* p, const KScene
     int rc = ensure(c, c->wfArena, off);
     if (rc) return rc;
     if (!c->aliveHost) {
-        HIP_TRY(c, hipHostMalloc(reinterpret_cast<void**>(&c->aliveHost), LRL_WF_MAX_ITERATIONS * 4, hipHostMallocDefault));
-        HIP_TRY(c, hipEventCreateWithFlags(&c->evIter[0], hipEventDisableTiming));
-        HIP_TRY(c, hipEventCreateWithFlags(&c->evIter[1], hipEventDisableTiming));
+        HIP_TRY(c, hipHostMalloc(reinterpret_cast<void**>(&c->aliveHost), LRL_WF_MAX_ITERATIONS * 4 * 2, hipHostMallocDefault));
+        HIP_TRY(c, hipHostGetDevicePointer(reinterpret_cast<void**>(&c->aliveHostDev), c->aliveHost, 0));
+        for (hipEvent_t& e : c->evIter) HIP_TRY(c, hipEventCreateWithFlags(&e, hipEventDisableTiming));
         HIP_TRY(c, hipHostMalloc(reinterpret_cast<void**>(&c->contHost), LRL_FEEDBACK_ITERS * 4 + LRL_FEEDBACK_ITERS * LRL_WORK_COUNTERS * 128, hipHostMallocDefault));
         HIP_TRY(c, hipEventCreateWithFlags(&c->evCont, hipEventDisableTiming));
     }
@@ -888,6 +890,8 @@ static int renderWavefront(LrlContext* c, const LrlRenderParams* p, const KScene
         if (FILE* fp = std::fopen(tlPath, "wb")) { std::fwrite(h.data(), 8, h.size(), fp); std::fclose(fp); }
         return LRL_OK;
     };
+    const char* lagEnv = std::getenv("LRL_POLL_LAG");
+    const uint32_t pollLag = lagEnv ? std::min(3u, std::max(1u, uint32_t(std::atoi(lagEnv)))) : 1u;
     const bool poll = c->hasTransmission;    // refraction stacks make the number of segments data dependent
     if (e0) HIP_TRY(c, hipEventRecord(e0, stream));
     uint32_t iterations = 0;
@@ -897,6 +901,10 @@ static int renderWavefront(LrlContext* c, const LrlRenderParams* p, const KScene
         // one fill (a size that is no multiple of 16 B costs a second fill kernel): alive, hand-over counts, work counters
         HIP_TRY(c, hipMemsetAsync(wf.alive, 0, special ? size_t(LRL_WF_MAX_ITERATIONS) * 8 + size_t(LRL_FEEDBACK_ITERS) * LRL_WORK_COUNTERS * 128
                                                        : size_t(LRL_WF_MAX_ITERATIONS) * 4, stream));
+        // polled words: the half of the pinned array that sample s - 2 used (the host has seen that sample end)
+        uint32_t* const aliveWords = c->aliveHost + size_t(s & 1u) * LRL_WF_MAX_ITERATIONS;
+        wf.aliveHost = poll ? c->aliveHostDev + size_t(s & 1u) * LRL_WF_MAX_ITERATIONS : nullptr;
+        if (poll) std::memset(aliveWords, 0, size_t(bound) * 4);
         HIP_TRY(c, fast ? lrl_fast::wfLaunchGenerate(k, f, wf, stream) : lrl_parity::wfLaunchGenerate(k, f, wf, stream));
         uint32_t iter = 0;
         for (; iter < bound; ++iter) {
@@ -906,19 +914,19 @@ static int renderWavefront(LrlContext* c, const LrlRenderParams* p, const KScene
             if (tl) { wf.timeline = nullptr; if ((rc = dumpTimeline())) return rc; }
             HIP_TRY(c, fast ? lrl_fast::wfLaunchShade(k, f, wf, iter, pool, stream) : lrl_parity::wfLaunchShade(k, f, wf, iter, pool, stream));
             if (!poll) continue;   // exact bound: nothing to ask the device, the whole frame is enqueued without a host wait
-            HIP_TRY(c, hipMemcpyAsync(c->aliveHost + iter, wf.alive + iter, 4, hipMemcpyDeviceToHost, stream));
-            HIP_TRY(c, hipEventRecord(c->evIter[iter & 1], stream));
-            if (iter >= 1) {      // look at the iteration before while this one runs: the pipeline ends one (empty) iteration late
-                HIP_TRY(c, hipEventSynchronize(c->evIter[(iter - 1) & 1]));
-                if (c->aliveHost[iter - 1] == 0) { ++iter; break; }
+            HIP_TRY(c, hipEventRecord(c->evIter[iter & 3], stream));
+            if (iter >= pollLag) {      // look at an earlier iteration while this one runs: the pipeline ends pollLag (empty) iterations late
+                HIP_TRY(c, hipEventSynchronize(c->evIter[(iter - pollLag) & 3]));
+                if (reinterpret_cast<volatile uint32_t*>(aliveWords)[iter - pollLag] == 0) { ++iter; break; }
             }
         }
         if (poll && iter == bound) {      // the last iteration has not been looked at yet
-            HIP_TRY(c, hipEventSynchronize(c->evIter[(bound - 1) & 1]));
-            if (c->aliveHost[bound - 1] != 0) return fail(c, LRL_ERR_LIMIT, "wavefront pipeline did not finish within its iteration bound");
+            HIP_TRY(c, hipEventSynchronize(c->evIter[(bound - 1) & 3]));
+            if (reinterpret_cast<volatile uint32_t*>(aliveWords)[bound - 1] != 0) return fail(c, LRL_ERR_LIMIT, "wavefront pipeline did not finish within its iteration bound");
         }
         iterations += iter;
-        if (special && c->contIters == 0) {      // (a copy still in flight is left alone)
+        // the feedback need not be fresh: the first samples after a scene upload, then one sample in eight (two copy kernels each)
+        if (special && c->contIters == 0 && (c->feedbackTick++ < 8 || (c->feedbackTick & 7u) == 0)) {      // (a copy still in flight is left alone)
             c->contIters = std::min(iter, LRL_FEEDBACK_ITERS);
             HIP_TRY(c, hipMemcpyAsync(c->contHost, contCounts, size_t(c->contIters) * 4, hipMemcpyDeviceToHost, stream));
             HIP_TRY(c, hipMemcpyAsync(c->contHost + LRL_FEEDBACK_ITERS, contWorkAll, size_t(c->contIters) * LRL_WORK_COUNTERS * 128, hipMemcpyDeviceToHost, stream));
