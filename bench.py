@@ -77,7 +77,7 @@ def main():
     if rehearse:
         local_rank = 0
         import faulthandler
-        faulthandler.dump_traceback_later(60, exit=True)      # a hang names its line
+        faulthandler.dump_traceback_later(180, exit=True)     # a hang names its line
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     if world > 1:
@@ -151,6 +151,11 @@ def main():
                 works[1 - b].wait()
                 works[1 - b] = None
             works[b] = dist.all_reduce(outs[b], op=dist.ReduceOp.SUM, async_op=True)
+        if rehearse:
+            print(f"[rehearsal] rank {rank}: step {counter[0]} queued", file=sys.stderr, flush=True)
+            if os.environ.get("LRL_BENCH_REHEARSE_SYNC") == "1":      # tells a render that never ends from a collective that never ends
+                render_stream.synchronize()
+                print(f"[rehearsal] rank {rank}: step {counter[0]} rendered", file=sys.stderr, flush=True)
 
     def drain():
         for i in (0, 1):

@@ -1124,6 +1124,15 @@ int lrl_last_kernel_ms(LrlContext* c, float* ms) {
 
 int lrl_timing_begin(LrlContext* c) {
     if (!c) return LRL_ERR_INVALID_ARG;
+    // the event pairs of a typical timed loop exist before it starts: creating events while another thread of the process
+    // sits in a HIP wait (a host-side collective's worker, as in bench.py's gloo rehearsal) stalled the loop
+    HIP_TRY(c, hipSetDevice(c->device));
+    while (c->timingEvents.size() < 256) {
+        hipEvent_t a, b;
+        HIP_TRY(c, hipEventCreate(&a));
+        HIP_TRY(c, hipEventCreate(&b));
+        c->timingEvents.emplace_back(a, b);
+    }
     c->timing = true;
     c->timingUsed = 0;
     return LRL_OK;
