@@ -804,6 +804,7 @@ static int renderWavefront(LrlContext* c, const LrlRenderParams* p, const KScene
     uint32_t swarmGroup = groupEnv ? uint32_t(std::atoi(groupEnv)) : 16u;
     if (swarmGroup != 8 && swarmGroup != 16 && swarmGroup != 32) swarmGroup = 64;
     if (swarmGroup != 64 && 2 * contStride + 3 * swarmGroup > LRL_GROUP_CAP) swarmGroup = 64;
+    const bool handoverFits = 2 * contStride + 192 <= LRL_SWARM_CAP;      // else (trees hundreds of levels deep) the lean kernel finishes every ray itself
     const char* sparseEnv = std::getenv("LRL_SPARSE_FROM");      // first iteration traced with the larger workgroups
     const uint32_t sparseFrom = sparseEnv ? uint32_t(std::atoi(sparseEnv)) : 5u;      // (measured: C2 best with none of its 5, C1 with 8 of its 56, C3 with 4 of its 10)
     const bool adapt = !(std::getenv("LRL_ADAPT") && std::atoi(std::getenv("LRL_ADAPT")) == 0);
@@ -874,7 +875,7 @@ static int renderWavefront(LrlContext* c, const LrlRenderParams* p, const KScene
         }
         if (special) {
             wf.contCount = contCounts + (iter < LRL_WF_MAX_ITERATIONS ? iter : 0);
-            wf.handoverTrips = c->handoverThr[std::min(iter, LRL_FEEDBACK_ITERS - 1)];
+            wf.handoverTrips = handoverFits ? c->handoverThr[std::min(iter, LRL_FEEDBACK_ITERS - 1)] : 0u;
             wf.contWork = contWorkAll + size_t(std::min(iter, LRL_FEEDBACK_ITERS - 1)) * LRL_WORK_COUNTERS * 32;
             HIP_TRY(c, lrl_fast::wfLaunchTraceLean(k, wf, iter >= sparseFrom, stream));
             if (wf.handoverTrips) HIP_TRY(c, lrl_fast::wfLaunchTraceSwarm(k, wf, c->swarmGrid[std::min(iter, LRL_FEEDBACK_ITERS - 1)], swarmGroup, stream));

@@ -332,6 +332,110 @@ def test_diffuse_bounce_vs_oracle(tracer, default_model, bunny0_model):
         tracer.render(max_depth=4, diffuse=True, megakernel=True)
 
 
+def chain_scene(n):
+    """n mirror triangles in a row under a degenerate caller-made tree: inner node k holds triangle k on the left and the
+    rest of the row on the right, so the tree is n levels deep (the reference's mean split makes such chains from
+    geometric progressions of sizes; here it is made by hand in the reference's 64-B pre-order layout)."""
+    m = host.HostModel()
+    t = np.zeros(n, dtype=abi.TRIANGLE)
+    x = np.arange(n, dtype=np.float32) * 0.5
+    zero = np.zeros(n, dtype=np.float32)
+    h = np.float32(0.15 * n)               # tall slats: the row fills a good part of the view
+    t["p1"] = np.stack([x, zero - h, zero], axis=1)
+    t["p2"] = np.stack([x + 0.45, zero - h, zero + 0.1], axis=1)
+    t["p3"] = np.stack([x + 0.2, zero + h, zero], axis=1)
+    t["uv2"], t["uv3"] = (1, 0), (0, 1)
+    for i in range(n):
+        t["color"][i] = abi.color(d=(0.3 + 0.7 * (i % 3 == 0), 0.3 + 0.7 * (i % 3 == 1), 0.3 + 0.7 * (i % 3 == 2)), r=0.5)
+    m.add_triangles(t)
+    g = np.zeros(1, dtype=abi.CIRCLE)      # a mirror floor behind the row, so that reflected rays come back through the chain
+    g["plane"], g["sphere"], g["e1"] = (0, 0, 1, 2), (n * 0.25, 0, -2, (n * 0.5) ** 2), (1, 0, 0)
+    g["color"] = abi.color(d=0.5, r=0.8)
+    m.add_circles(g)
+    L = np.zeros(1, dtype=abi.POINTLIGHT)
+    L["color"], L["p"] = (400, 400, 400), (n * 0.25, -3, 25)
+    m.add_point_lights(L)
+    m.set_cube_raw(np.full((6, 4, 4, 3), 90, dtype=np.uint8))
+    m.data_init("reference")               # a valid view (counts, leaf boxes); its tree is replaced below
+    m.camera_look_at(50.0, (n * 0.25, -0.5 * n - 4, 0.45 * n + 4), (n * 0.25, 0, 0))
+    v = m.scene_view()
+    lo = np.minimum(np.minimum(t["p1"], t["p2"]), t["p3"])
+    hi = np.maximum(np.maximum(t["p1"], t["p2"]), t["p3"])
+    ref = abi.scene_view_arrays(v)["bvh"]
+    disc = ref[ref["geometry"] == 4][0]                     # the floor's leaf box, as the host builder made it
+    nodes = np.zeros(2 * (n + 1) - 1, dtype=abi.BVHNODE)
+    # root: left = the floor disc, right = the chain over the triangles
+    suffix_lo = np.minimum.accumulate(lo[::-1], axis=0)[::-1]
+    suffix_hi = np.maximum.accumulate(hi[::-1], axis=0)[::-1]
+    nodes[0]["min"], nodes[0]["max"] = np.minimum(disc["min"], suffix_lo[0]), np.maximum(disc["max"], suffix_hi[0])
+    nodes[0]["leftChild"], nodes[0]["rightChild"], nodes[0]["axis"] = 1, 2, 2
+    nodes[1] = disc
+    nodes[1]["father"], nodes[1]["leftChild"], nodes[1]["rightChild"] = 0, 0, 0
+    at = 2
+    father = 0
+    for k in range(n - 1):
+        nodes[at]["min"], nodes[at]["max"] = suffix_lo[k], suffix_hi[k]
+        nodes[at]["leftChild"], nodes[at]["rightChild"], nodes[at]["father"], nodes[at]["axis"] = 1, at + 2, father, 0
+        leaf = nodes[at + 1]
+        leaf["min"], leaf["max"], leaf["father"], leaf["geometry"], leaf["geometryNum"] = lo[k], hi[k], at, 2, k
+        father = at
+        at += 2
+    last = nodes[at]
+    last["min"], last["max"], last["father"], last["geometry"], last["geometryNum"] = lo[n - 1], hi[n - 1], father, 2, n - 1
+    nodes = nodes[:at + 1]
+    chain_scene.keep = nodes
+    v.bvh = nodes.ctypes.data
+    v.bvhNodeNum = len(nodes)
+    return m, v
+
+
+@pytest.mark.parametrize("n", [60, 92, 140])
+def test_deep_chain_tree(tracer, n):
+    """Trees far deeper than the LDS stacks: 61 and 93 levels (the traversal stacks spill to their global overflow, the
+    hand-over records are 62 and 95 refs long: the deeper one nearly fills a 16-lane group's share of the frontier, so its
+    rounds run depth-first), and 141 levels: beyond LRL_MAX_BVH_DEPTH, refused with its own error code.  PARITY against the oracle, FAST against both; then with a
+    hand-over after 4 trips so that the continuation kernels do most of the work."""
+    m, v = chain_scene(n)
+    if n > 95:
+        from raytracing_amd.tracer import TraceError
+        with pytest.raises(TraceError) as e:
+            tracer.scene_upload(v)
+        assert e.value.code == 4                           # LRL_ERR_BVH_DEPTH
+        return
+    W, H = 128, 96
+    tr = m.camera(H)
+    tracer.scene_upload(v)
+    tracer.set_camera(tr, W, H)
+    tracer.set_decay_origin((0, 0, 0, 1))
+    # the oracle keeps the shader's trail in 64-bit masks (the shader: 32), so beyond 64 levels it walks the same scene
+    # under the host builder's own shallow tree: the picture does not depend on the tree
+    oimg, ohits, oc = O.render(v if n <= 60 else m.scene_view(), tr, W, H, max_depth=4, threads=8)
+    assert (ohits[..., 0] == 2).mean() > 0.05              # the row is in view
+    img, hits = tracer.render(max_depth=4, mode=abi.MODE_PARITY, counters=True)
+    assert (hits == ohits).all(axis=-1).mean() >= ID_BAR and image_stats(img, oimg)["rmse"] <= RMSE_PARITY
+    if n <= 60:
+        assert tracer.counters().nodeVisits == oc.nodeVisits
+    assert tracer.counters().rays == oc.rays
+    saved = {k: os.environ.get(k) for k in ("LRL_ADAPT", "LRL_HANDOVER_LIST")}
+    try:
+        for early in (False, True):
+            if early:
+                os.environ.update(LRL_ADAPT="0", LRL_HANDOVER_LIST="4")
+                tracer.scene_upload(v)
+                tracer.set_camera(tr, W, H)
+                tracer.set_decay_origin((0, 0, 0, 1))
+            fast, fhits = tracer.render(max_depth=4, mode=abi.MODE_FAST)
+            assert (fhits == ohits).all(axis=-1).mean() >= ID_BAR, early
+            assert image_stats(fast, oimg)["rmse"] <= RMSE_FAST, early
+    finally:
+        for k, val in saved.items():
+            if val is None:
+                os.environ.pop(k, None)
+            else:
+                os.environ[k] = val
+        tracer.scene_upload(v)                              # thresholds back to their defaults for the tests that follow
+
+
 def test_hand_over_kernels_agree(default_model, bunny0_model):
     """FAST mode's continuation kernels (16 lanes per ray, and one wave per ray for deep trees) keep no visit order; the
     closest hit must come out all the same.  With a threshold of 4 trips nearly every ray goes through them: both must
