@@ -158,6 +158,8 @@ struct WFrame {
     uint32_t* aliveHost;     // the same words in pinned host memory when the host polls them (scenes with transmission), else NULL
     // hand-over of long chains (lrl_lean.inc -> wfTraceSwarmKernel): a ray still going after `handoverTrips` trips leaves
     // its pending work here and a whole wave finishes it
+    uint32_t* rayList;       // [kind][P]: the live rays of the iteration, compacted (wfCompactKernel), for the late, sparse segments
+    uint32_t* listCount;     // [kind] for this iteration, zeroed with the frame's counters
     uint32_t* contWork;      // LRL_WORK_COUNTERS counters, 128 B apart: frontier entries the hand-over kernel tested in this iteration
     uint32_t handoverTrips;  // 0: never hand over
     uint32_t contSlots;      // capacity of contHead / contRefs
@@ -180,7 +182,7 @@ struct WFrame {
 LRL_WF_DECLARE(lrl_parity)
 LRL_WF_DECLARE(lrl_fast)
 namespace lrl_fast {
-hipError_t wfLaunchTraceLean(const KScene& sc, const WFrame& wf, bool sparse, hipStream_t stream);   // sparse: few rays in many words (larger workgroups)
+hipError_t wfLaunchTraceLean(const KScene& sc, const WFrame& wf, bool sparse, bool compact, hipStream_t stream);   // sparse: few rays in many words (larger workgroups)
 hipError_t wfLaunchTraceSwarm(const KScene& sc, const WFrame& wf, uint32_t waves, uint32_t group, hipStream_t stream);
 }
 

@@ -735,6 +735,7 @@ int lrl_compute_decay_origin(LrlContext* c, uint32_t variant, LrlDecayOrigin* ou
 // ---- wavefront pipeline: generate, then (trace, shade) per ray segment until no path is alive ----
 #define LRL_WF_MAX_ITERATIONS 4096u
 #define LRL_FEEDBACK_ITERS 64u
+#define LRL_LIST_KINDS 8u        /* ray kinds (closest + one shadow ray per light) the compacted lists are kept for */
 static int renderWavefront(LrlContext* c, const LrlRenderParams* p, const KScene& k, KFrame f, float* rgbaDev, uint32_t* hitDev,
                            unsigned long long* ctr, hipStream_t stream, uint32_t rows, hipEvent_t e0, hipEvent_t e1) {
     const bool fast = p->mode == LRL_MODE_FAST, pool = p->variant == LRL_VARIANT_POOL;
@@ -765,6 +766,7 @@ static int renderWavefront(LrlContext* c, const LrlRenderParams* p, const KScene
     const char* slotsEnv = std::getenv("LRL_CONT_SLOTS");
     const uint32_t contSlots = slotsEnv ? std::max(1024u, uint32_t(std::atoi(slotsEnv))) : 262144u, contStride = stackNeed + 1;
     const size_t oContHead = take(size_t(contSlots) * 16), oContRefs = take(size_t(contSlots) * contStride * 4);
+    const size_t oRayList = take(special ? P * (1 + size_t(L)) * 4 : 0), oListCount = take(special ? size_t(LRL_WF_MAX_ITERATIONS) * LRL_LIST_KINDS * 4 : 0);
     int rc = ensure(c, c->wfArena, off);
     if (rc) return rc;
     if (!c->aliveHost) {
@@ -847,6 +849,17 @@ static int renderWavefront(LrlContext* c, const LrlRenderParams* p, const KScene
     wf.contHead = reinterpret_cast<uint4*>(base + oContHead);
     wf.contRefs = reinterpret_cast<uint32_t*>(base + oContRefs);
     wf.contCount = contCounts;
+    wf.rayList = reinterpret_cast<uint32_t*>(base + oRayList);
+    uint32_t* const listCounts = reinterpret_cast<uint32_t*>(base + oListCount);      // [iteration][LRL_LIST_KINDS]
+    wf.listCount = listCounts;
+    // compaction of the live rays before the trace launches of the late segments (LRL_COMPACT_FROM: first such iteration,
+    // 0 = never).  It pays where the survivors are scattered over the mask words or a trip is expensive: after diffuse
+    // bounces (C2 with them: 2.07 -> 1.60 ms) and on scenes far beyond the caches (100 M triangles: 2.84 -> 2.62 ms; C5:
+    // 141.5 -> 132.6 ms); on C2 itself, the Pool and the default scene the extra kernel per iteration costs 1.5-10 %.
+    // With more kinds of rays than LRL_LIST_KINDS (lights + 1) the masks are used throughout.
+    const char* cfEnv = std::getenv("LRL_COMPACT_FROM");
+    const uint32_t compactFrom = (1 + L > LRL_LIST_KINDS) ? 0u : cfEnv ? uint32_t(std::atoi(cfEnv))
+                                 : (f.diffuse || size_t(c->recNum) * 64 > (size_t(1) << 30)) ? 2u : 0u;
     wf.out = reinterpret_cast<float4*>(rgbaDev);
     wf.hitOut = reinterpret_cast<uint2*>(hitDev);
     wf.counters = ctr;
@@ -877,7 +890,9 @@ static int renderWavefront(LrlContext* c, const LrlRenderParams* p, const KScene
             wf.contCount = contCounts + (iter < LRL_WF_MAX_ITERATIONS ? iter : 0);
             wf.handoverTrips = handoverFits ? c->handoverThr[std::min(iter, LRL_FEEDBACK_ITERS - 1)] : 0u;
             wf.contWork = contWorkAll + size_t(std::min(iter, LRL_FEEDBACK_ITERS - 1)) * LRL_WORK_COUNTERS * 32;
-            HIP_TRY(c, lrl_fast::wfLaunchTraceLean(k, wf, iter >= sparseFrom, stream));
+            const bool compact = compactFrom != 0 && iter >= compactFrom && iter < LRL_WF_MAX_ITERATIONS;
+            wf.listCount = listCounts + size_t(iter < LRL_WF_MAX_ITERATIONS ? iter : 0) * LRL_LIST_KINDS;
+            HIP_TRY(c, lrl_fast::wfLaunchTraceLean(k, wf, iter >= sparseFrom, compact, stream));
             if (wf.handoverTrips) HIP_TRY(c, lrl_fast::wfLaunchTraceSwarm(k, wf, c->swarmGrid[std::min(iter, LRL_FEEDBACK_ITERS - 1)], swarmGroup, stream));
         }
         else HIP_TRY(c, fast ? lrl_fast::wfLaunchTrace(k, wf, stream) : lrl_parity::wfLaunchTrace(k, wf, stream));
@@ -902,6 +917,8 @@ static int renderWavefront(LrlContext* c, const LrlRenderParams* p, const KScene
         // one fill (a size that is no multiple of 16 B costs a second fill kernel): alive, hand-over counts, work counters
         HIP_TRY(c, hipMemsetAsync(wf.alive, 0, special ? size_t(LRL_WF_MAX_ITERATIONS) * 8 + size_t(LRL_FEEDBACK_ITERS) * LRL_WORK_COUNTERS * 128
                                                        : size_t(LRL_WF_MAX_ITERATIONS) * 4, stream));
+        if (special && compactFrom != 0 && bound > compactFrom)
+            HIP_TRY(c, hipMemsetAsync(listCounts, 0, size_t(bound) * LRL_LIST_KINDS * 4, stream));
         // polled words: the half of the pinned array that sample s - 2 used (the host has seen that sample end)
         uint32_t* const aliveWords = c->aliveHost + size_t(s & 1u) * LRL_WF_MAX_ITERATIONS;
         wf.aliveHost = poll ? c->aliveHostDev + size_t(s & 1u) * LRL_WF_MAX_ITERATIONS : nullptr;

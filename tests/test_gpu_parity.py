@@ -436,6 +436,32 @@ def test_deep_chain_tree(tracer, n):
         tracer.scene_upload(v)                              # thresholds back to their defaults for the tests that follow
 
 
+def test_compacted_ray_lists_change_nothing(tracer, default_model, bunny0_model):
+    """FAST mode may trace the late segments from compacted lists of the live rays (on by default after diffuse bounces and
+    for scenes beyond the caches; LRL_COMPACT_FROM forces it).  A ray's result does not depend on the lane that carries it:
+    the frames with and without compaction are the same bit for bit, mirror and diffuse."""
+    saved = os.environ.get("LRL_COMPACT_FROM")
+    try:
+        for m, (W, H) in ((default_model, (200, 160)), (bunny0_model, (320, 180))):
+            tr = m.camera(H)
+            tracer.scene_upload(m.scene_view())
+            tracer.set_camera(tr, W, H)
+            tracer.set_decay_origin((0, 0, 0, 1))
+            for diffuse in (False, True):
+                frames = {}
+                for start in ("0", "1", "3"):
+                    os.environ["LRL_COMPACT_FROM"] = start
+                    frames[start] = tracer.render(max_depth=6, mode=abi.MODE_FAST, diffuse=diffuse)
+                for start in ("1", "3"):
+                    assert np.array_equal(frames[start][0], frames["0"][0]), (diffuse, start)
+                    assert np.array_equal(frames[start][1], frames["0"][1]), (diffuse, start)
+    finally:
+        if saved is None:
+            os.environ.pop("LRL_COMPACT_FROM", None)
+        else:
+            os.environ["LRL_COMPACT_FROM"] = saved
+
+
 def test_hand_over_kernels_agree(default_model, bunny0_model):
     """FAST mode's continuation kernels (16 lanes per ray, and one wave per ray for deep trees) keep no visit order; the
     closest hit must come out all the same.  With a threshold of 4 trips nearly every ray goes through them: both must
