@@ -124,7 +124,7 @@ enum { LRL_CTR_PRIMARY = 0, LRL_CTR_REFLECT, LRL_CTR_REFRACT, LRL_CTR_SHADOW, LR
 #endif
 #define LRL_WORK_COUNTERS 4u         /* per iteration, 128 B apart: sampled work of the hand-over kernels (feedback) */
 #ifndef LRL_GROUP_CAP
-#define LRL_GROUP_CAP 256u           /* frontier entries of one ray in the lanes-per-ray kernel (tests build it smaller) */
+#define LRL_GROUP_CAP 256u           /* smallest frontier of one ray in the lanes-per-ray kernel (tests build it smaller); doubled for deep trees */
 #endif
 #define LRL_WF_SLOT_ALIGN (64u * LRL_WF_CHUNK_WORDS > 256u ? 64u * LRL_WF_CHUNK_WORDS : 256u)
 
@@ -160,6 +160,7 @@ struct WFrame {
     // its pending work here and a whole wave finishes it
     uint32_t* rayList;       // [kind][P]: the live rays of the iteration, compacted (wfCompactKernel), for the late, sparse segments
     uint32_t* listCount;     // [kind] for this iteration, zeroed with the frame's counters
+    uint32_t groupCap;       // frontier entries per ray of the lanes-per-ray kernel (LRL_GROUP_CAP or twice that: picks the instantiation)
     uint32_t* contWork;      // LRL_WORK_COUNTERS counters, 128 B apart: frontier entries the hand-over kernel tested in this iteration
     uint32_t handoverTrips;  // 0: never hand over
     uint32_t contSlots;      // capacity of contHead / contRefs

@@ -805,7 +805,11 @@ static int renderWavefront(LrlContext* c, const LrlRenderParams* p, const KScene
     const char* groupEnv = std::getenv("LRL_SWARM_GROUP");
     uint32_t swarmGroup = groupEnv ? uint32_t(std::atoi(groupEnv)) : 16u;
     if (swarmGroup != 8 && swarmGroup != 16 && swarmGroup != 32) swarmGroup = 64;
-    if (swarmGroup != 64 && 2 * contStride + 3 * swarmGroup > LRL_GROUP_CAP) swarmGroup = 64;
+    // a ray's frontier: LRL_GROUP_CAP entries, twice that where the hand-over record + depth-first reserve (contStride) would
+    // leave less than half of it for full rounds (LRL_GROUP_CAP_X: 1 or 2 times; groups of 16 lanes only)
+    const char* capEnv = std::getenv("LRL_GROUP_CAP_X");
+    const uint32_t groupCap = LRL_GROUP_CAP * ((swarmGroup == 16 && (capEnv ? std::atoi(capEnv) >= 2 : 2 * contStride + 3 * swarmGroup > LRL_GROUP_CAP / 2 + 64)) ? 2u : 1u);
+    if (swarmGroup != 64 && 2 * contStride + 3 * swarmGroup > groupCap) swarmGroup = 64;
     const bool handoverFits = 2 * contStride + 192 <= LRL_SWARM_CAP;      // else (trees hundreds of levels deep) the lean kernel finishes every ray itself
     const char* sparseEnv = std::getenv("LRL_SPARSE_FROM");      // first iteration traced with the larger workgroups
     const uint32_t sparseFrom = sparseEnv ? uint32_t(std::atoi(sparseEnv)) : 5u;      // (measured: C2 best with none of its 5, C1 with 8 of its 56, C3 with 4 of its 10)
@@ -845,7 +849,7 @@ static int renderWavefront(LrlContext* c, const LrlRenderParams* p, const KScene
         c->contIters = 0;
     };
     wf.handoverTrips = handoverEarly;
-    wf.contSlots = contSlots; wf.contStride = contStride;
+    wf.contSlots = contSlots; wf.contStride = contStride; wf.groupCap = groupCap;
     wf.contHead = reinterpret_cast<uint4*>(base + oContHead);
     wf.contRefs = reinterpret_cast<uint32_t*>(base + oContRefs);
     wf.contCount = contCounts;
