@@ -806,9 +806,9 @@ static int renderWavefront(LrlContext* c, const LrlRenderParams* p, const KScene
     uint32_t swarmGroup = groupEnv ? uint32_t(std::atoi(groupEnv)) : 16u;
     if (swarmGroup != 8 && swarmGroup != 16 && swarmGroup != 32) swarmGroup = 64;
     // a ray's frontier: LRL_GROUP_CAP entries, twice that where the hand-over record + depth-first reserve (contStride) would
-    // leave less than half of it for full rounds (LRL_GROUP_CAP_X: 1 or 2 times; groups of 16 lanes only)
+    // leave less than 2/5 of it for full rounds (LRL_GROUP_CAP_X: 1 or 2 times; groups of 16 lanes only)
     const char* capEnv = std::getenv("LRL_GROUP_CAP_X");
-    const uint32_t groupCap = LRL_GROUP_CAP * ((swarmGroup == 16 && (capEnv ? std::atoi(capEnv) >= 2 : 2 * contStride + 3 * swarmGroup > LRL_GROUP_CAP / 2 + 64)) ? 2u : 1u);
+    const uint32_t groupCap = LRL_GROUP_CAP * ((swarmGroup == 16 && (capEnv ? std::atoi(capEnv) >= 2 : 2 * contStride + 3 * swarmGroup > LRL_GROUP_CAP - 32)) ? 2u : 1u);      // C2 (stride 77): 256 is 1.3 % faster; 100 M device-built tree (95): 512 is 1.85x faster on C5
     if (swarmGroup != 64 && 2 * contStride + 3 * swarmGroup > groupCap) swarmGroup = 64;
     const bool handoverFits = 2 * contStride + 192 <= LRL_SWARM_CAP;      // else (trees hundreds of levels deep) the lean kernel finishes every ray itself
     const char* sparseEnv = std::getenv("LRL_SPARSE_FROM");      // first iteration traced with the larger workgroups
