@@ -135,9 +135,25 @@ def main():
     render_stream = torch.cuda.Stream(device=dev) if world > 1 else None
     counter = [0]
 
+    # LRL_BENCH_OVERLAP=1: the all-reduce of frame i overlaps the render of frame i + 1 (two buffers, one collective in
+    # flight).  Not the default: its two-rank rehearsal over gloo (whose collectives block a worker thread inside HIP waits)
+    # stalled now and then in the timed loop, and a stalled scaling run measures nothing; RCCL has no such thread, so the
+    # overlap is there to be switched on once it has run on a multi-GPU node.
+    overlap = os.environ.get("LRL_BENCH_OVERLAP") == "1"
+
     def step():
         if world == 1:
             tr.render_device(out.data_ptr(), max_depth=a.depth, variant=variant, mode=mode, jitter=jitter, samples=samples, diffuse=a.diffuse)
+            return
+        if not overlap:
+            # default: the frame and its all-reduce one after the other on one stream (RCCL: both are only enqueued)
+            counter[0] += 1
+            with torch.cuda.stream(render_stream):
+                tr.render_device(outs[0].data_ptr(), stream=render_stream.cuda_stream, max_depth=a.depth, variant=variant, mode=mode,
+                                 jitter=jitter, samples=samples, diffuse=a.diffuse)
+                dist.all_reduce(outs[0], op=dist.ReduceOp.SUM)
+            if rehearse:
+                print(f"[rehearsal] rank {rank}: step {counter[0]} done", file=sys.stderr, flush=True)
             return
         b = counter[0] & 1
         counter[0] += 1
