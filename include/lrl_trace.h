@@ -121,11 +121,37 @@ typedef struct LrlCounters {
     uint64_t primaryHits;
 } LrlCounters;
 
+/* Scheduling knobs of the FAST-mode pipeline (no counterpart in the reference, whose driver schedules its fragment shader).
+ * None of them changes which primitive a ray hits except at exact ties (FAST bars, tests/test_gpu_parity.py); PARITY renders
+ * ignore all but batchSlots / pollLag / debug.  lrl_create sets the defaults; lrl_set_tuning replaces them (and resets the
+ * adaptive thresholds).  The library reads no environment variable on the render path. */
+#define LRL_TUNING_LIST_MAX 8u
+typedef struct LrlTuning {
+    uint32_t handoverEarly;      /* lean kernel: trips after which a ray still going is handed to the lanes-per-ray kernel, */
+    uint32_t handoverLate;       /*   first two segments / later segments (48 / 16; 0 = never hand over)                    */
+    uint32_t handoverListLen;    /* > 0: explicit thresholds per segment instead (the last one repeats)                     */
+    uint32_t handoverList[LRL_TUNING_LIST_MAX];
+    uint32_t adapt;              /* 1: thresholds ratchet up from the sampled work counters of earlier frames               */
+    uint32_t groupLanes;         /* lanes per handed-over ray: 8, 16 (default), 32, or 64 (a wave per ray)                  */
+    uint32_t contSlots;          /* hand-over records per launch; 0 = 262144 per 2^21 path slots of a launch                */
+    uint32_t groupCapX;          /* frontier entries per ray = 256 x this; 0 = by tree depth (1 or 2)                       */
+    uint32_t sparseFrom;         /* first segment traced with four-wave workgroups (5)                                      */
+    int32_t  compactFrom;        /* first segment traced from compacted ray lists; 0 never; -1 = by regime                  */
+    float    workLow;            /* frontier entries per handed-over ray below which a threshold doubles (12)               */
+    uint32_t pollLag;            /* scenes with transmission: iterations the host polls behind the queue (1..3)             */
+    uint32_t traceRef;           /* 1: FAST arithmetic on the reference-order kernel (diagnostic)                           */
+    uint32_t batchSlots;         /* spp > 1: samples are traced together up to this many path slots per launch;             */
+                                 /*   0 = 2^23 (the chip fills at about 8 M rays per launch)                                */
+    uint32_t debug;              /* 1: per-frame diagnostics on stderr (adds host waits); 2: + a line around every HIP call */
+} LrlTuning;
+
 /* ---- life cycle ---- */
 int lrl_create(int device, LrlContext** out);
 int lrl_destroy(LrlContext* ctx);
 const char* lrl_last_error(const LrlContext* ctx);   /* never NULL */
 int lrl_version(void);
+int lrl_get_tuning(const LrlContext* ctx, LrlTuning* out);
+int lrl_set_tuning(LrlContext* ctx, const LrlTuning* tuning);
 
 /* ---- scene (model.dataInit) ---- */
 int lrl_scene_upload(LrlContext* ctx, const LrlSceneView* scene);
@@ -145,7 +171,7 @@ int lrl_compute_decay_origin(LrlContext* ctx, uint32_t variant, LrlDecayOrigin* 
 /* ---- the frame (renderer.run) ---- */
 int lrl_render(LrlContext* ctx, const LrlRenderParams* params,
                float* rgba_out /* W*(rowEnd-rowBegin)*4 floats */,
-               uint32_t* hit_out /* optional: per pixel {type, index} of the primary hit, 0 = miss */);
+               uint32_t* hit_out /* optional: per pixel {type, index} of the primary hit (of the first sample rendered), 0 = miss */);
 int lrl_render_async(LrlContext* ctx, const LrlRenderParams* params, float* rgba_out_dev, uint32_t* hit_out_dev,
                      void* hip_stream);
 int lrl_sync(LrlContext* ctx);

@@ -60,6 +60,14 @@ class RenderParams(C.Structure):
                 ("sampleEnd", C.c_uint32)]
 
 
+class Tuning(C.Structure):
+    """LrlTuning (include/lrl_trace.h): scheduling knobs of the FAST pipeline."""
+    _fields_ = [("handoverEarly", C.c_uint32), ("handoverLate", C.c_uint32), ("handoverListLen", C.c_uint32), ("handoverList", C.c_uint32 * 8),
+                ("adapt", C.c_uint32), ("groupLanes", C.c_uint32), ("contSlots", C.c_uint32), ("groupCapX", C.c_uint32), ("sparseFrom", C.c_uint32),
+                ("compactFrom", C.c_int32), ("workLow", C.c_float), ("pollLag", C.c_uint32), ("traceRef", C.c_uint32), ("batchSlots", C.c_uint32),
+                ("debug", C.c_uint32)]
+
+
 class Counters(C.Structure):
     _fields_ = [(n, C.c_uint64) for n in ("raysPrimary", "raysReflect", "raysRefract", "raysShadow", "nodeVisits", "triTests",
                                           "sphereTests", "otherTests", "primaryHits")]

@@ -122,6 +122,7 @@ enum { LRL_CTR_PRIMARY = 0, LRL_CTR_REFLECT, LRL_CTR_REFRACT, LRL_CTR_SHADOW, LR
 #ifndef LRL_SWARM_CAP
 #define LRL_SWARM_CAP 1024         /* frontier entries of the wave-per-ray continuation kernel (LDS) */
 #endif
+#define LRL_FEEDBACK_ITERS 64u        /* iterations (ray segments) whose hand-over thresholds adapt */
 #define LRL_WORK_COUNTERS 4u         /* per iteration, 128 B apart: sampled work of the hand-over kernels (feedback) */
 #ifndef LRL_GROUP_CAP
 #define LRL_GROUP_CAP 256u           /* smallest frontier of one ray in the lanes-per-ray kernel (tests build it smaller); doubled for deep trees */
@@ -136,10 +137,15 @@ enum { LRL_CTR_PRIMARY = 0, LRL_CTR_REFLECT, LRL_CTR_REFRACT, LRL_CTR_SHADOW, LR
 #define LRL_WF_SP_SHIFT 12    /* 4 bits: refraction stack entries */
 
 struct WFrame {
-    uint32_t P;              // path slots, multiple of LRL_WF_SLOT_ALIGN
+    uint32_t P;              // path slots of this pass = batch x Ppix, multiple of LRL_WF_SLOT_ALIGN
     uint32_t words;          // P / 64
     uint32_t tilesX;         // 8x8 tiles per row of tiles
-    uint32_t sample;         // sample index rendered by this pass
+    uint32_t sample;         // first sample index rendered by this pass
+    uint32_t batch;          // samples traced together by this pass: slot = b * Ppix + pixel slot, sample = `sample` + b
+    uint32_t Ppix;           // path slots of one sample (pixels in 8x8-tile-major order, padded)
+    uint32_t blocksPerSample;   // Ppix / 256: a 256-thread block of generate / shade never straddles two samples
+    uint32_t* feedbackHost;  // pinned host memory (device address), [iteration][8]: hand-over count + work counters of this pass, written by the
+                             // shade kernel's first block (no copy on the caller's stream); NULL: not this pass
     uint32_t overflowEntries;   // per-lane entries of `overflow` (0: the LDS stack always suffices)
     uint32_t tilesY;         // rows of tiles
     float4* answer;          // xyz accumulated colour, w = v of the pending light terms
@@ -179,6 +185,7 @@ struct WFrame {
     hipError_t wfLaunchGenerate(const KScene& sc, const KFrame& fr, const WFrame& wf, hipStream_t stream);            \
     hipError_t wfLaunchTrace(const KScene& sc, const WFrame& wf, hipStream_t stream);                                 \
     hipError_t wfLaunchShade(const KScene& sc, const KFrame& fr, const WFrame& wf, uint32_t iter, bool pool, hipStream_t stream); \
+    hipError_t wfLaunchAccumulate(const KFrame& fr, const WFrame& wf, hipStream_t stream);                            \
     }
 LRL_WF_DECLARE(lrl_parity)
 LRL_WF_DECLARE(lrl_fast)

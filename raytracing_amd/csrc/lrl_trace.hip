@@ -14,6 +14,8 @@
 
 #include "lrl_device.h"
 
+#define LRL_WF_MAX_ITERATIONS 4096u   /* ray segments of one path the wavefront pipeline follows at most */
+
 namespace {
 
 struct DevBuf {
@@ -67,8 +69,14 @@ struct LrlContext {
     uint32_t* aliveHostDev = nullptr;   // the device's address of the same memory
     // feedback for the hand-over thresholds of the FAST trace kernels: rays handed over per iteration of the last finished
     // sample (pinned copy, read when its event has completed: never waited for)
-    uint32_t* contHost = nullptr;
+    uint32_t* contHost = nullptr;       // pinned, [LRL_FEEDBACK_ITERS][8]: {rays handed over, LRL_WORK_COUNTERS work counters} written by the shade kernel
+    uint32_t* contHostDev = nullptr;    // the device's address of the same memory
+    uint32_t contSlotsInFlight = 0;     // hand-over slots of the pass whose feedback is in flight
     hipEvent_t evCont = nullptr;
+    hipEvent_t evLastRender = nullptr;  // recorded behind every render: a render on another stream waits for it (the arena is shared)
+    hipStream_t lastRenderStream = nullptr;
+    bool renderedOnce = false;
+    LrlTuning tuning{};
     std::vector<float> workPerRay;      // per iteration: frontier entries per handed-over ray, last feedback
     uint32_t feedbackTick = 0;          // samples rendered since the thresholds were reset
     uint32_t contIters = 0;             // words of contHost in flight / ready
@@ -395,6 +403,7 @@ int runDeviceBuild(LrlContext* c, uint32_t prims, uint32_t& recCount, uint32_t& 
     if ((rc = ensure(c, c->nodes32, size_t(recCount) * 64))) return rc;
     if (prims == 1) {      // one primitive: the virtual parent of a leaf
         float4 mn, mx;
+        HIP_TRY(c, hipStreamSynchronize(c->stream));      // the boxes may come from a triangle update still in flight (lrl_scene_rebuild_bvh)
         HIP_TRY(c, hipMemcpy(&mn, c->primMin.p, 16, hipMemcpyDeviceToHost));
         HIP_TRY(c, hipMemcpy(&mx, c->primMax.p, 16, hipMemcpyDeviceToHost));
         uint32_t bits; std::memcpy(&bits, &mn.w, 4);
@@ -424,11 +433,11 @@ int runDeviceBuild(LrlContext* c, uint32_t prims, uint32_t& recCount, uint32_t& 
         c->node4Depth = 1;
         return LRL_OK;
     }
-    const size_t scratch = lrl_build_scratch_bytes(prims);
-    if ((rc = ensure(c, c->buildScratch, scratch))) return rc;
+    const size_t buildBytes = lrl_build_scratch_bytes(prims);
+    if ((rc = ensure(c, c->buildScratch, buildBytes))) return rc;
     if ((rc = ensure(c, c->buildInfo, 256))) return rc;
     HIP_TRY(c, lrl_build_bvh(static_cast<const float4*>(c->primMin.p), static_cast<const float4*>(c->primMax.p), prims, static_cast<float4*>(c->nodes.p),
-                             static_cast<uint4*>(c->nodes32.p), c->buildScratch.p, scratch, static_cast<uint32_t*>(c->buildInfo.p), c->stream));
+                             static_cast<uint4*>(c->nodes32.p), c->buildScratch.p, buildBytes, static_cast<uint32_t*>(c->buildInfo.p), c->stream));
     uint32_t info[2] = {0, 0};
     HIP_TRY(c, hipMemcpyAsync(info, c->buildInfo.p, 8, hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(c, hipStreamSynchronize(c->stream));
@@ -436,15 +445,42 @@ int runDeviceBuild(LrlContext* c, uint32_t prims, uint32_t& recCount, uint32_t& 
     if (info[0] + 1 > LRL_MAX_BVH_DEPTH) return fail(c, LRL_ERR_BVH_DEPTH, "device-built BVH deeper than LRL_MAX_BVH_DEPTH");
     depth = info[0];
     c->node4Depth = info[1];
-    if (scratch > (64u << 20)) release(c->buildScratch);      // the tree is built: only the records stay (small scratch is kept for rebuilds)
+    if (buildBytes > (64u << 20)) release(c->buildScratch);      // the tree is built: only the records stay (small scratch is kept for rebuilds)
     return LRL_OK;
 }
+
+LrlTuning defaultTuning() {
+    LrlTuning t{};
+    t.handoverEarly = 48; t.handoverLate = 16; t.handoverListLen = 0;
+    t.adapt = 1; t.groupLanes = 16; t.contSlots = 0; t.groupCapX = 0; t.sparseFrom = 5; t.compactFrom = -1;
+    t.workLow = 12.0f; t.pollLag = 1; t.traceRef = 0; t.batchSlots = 0; t.debug = 0;
+    return t;
+}
+
+#ifdef LRL_DIAG
+void tuningFromEnv(LrlTuning& t) {
+    auto u = [](const char* name, uint32_t& v) { if (const char* e = std::getenv(name)) v = uint32_t(std::strtoul(e, nullptr, 10)); };
+    u("LRL_HANDOVER", t.handoverEarly); u("LRL_HANDOVER_LATE", t.handoverLate); u("LRL_ADAPT", t.adapt); u("LRL_SWARM_GROUP", t.groupLanes);
+    u("LRL_CONT_SLOTS", t.contSlots); u("LRL_GROUP_CAP_X", t.groupCapX); u("LRL_SPARSE_FROM", t.sparseFrom); u("LRL_POLL_LAG", t.pollLag);
+    u("LRL_BATCH_SLOTS", t.batchSlots); u("LRL_DEBUG", t.debug);
+    if (const char* e = std::getenv("LRL_COMPACT_FROM")) t.compactFrom = std::atoi(e);
+    if (const char* e = std::getenv("LRL_WORK_LOW")) t.workLow = float(std::atof(e));
+    if (const char* e = std::getenv("LRL_TRACE")) t.traceRef = !std::strcmp(e, "ref");
+    if (const char* tl = std::getenv("LRL_HANDOVER_LIST")) {
+        t.handoverListLen = 0;
+        for (const char* q = tl; *q && t.handoverListLen < LRL_TUNING_LIST_MAX;) {
+            t.handoverList[t.handoverListLen++] = uint32_t(std::strtoul(q, const_cast<char**>(&q), 10));
+            if (*q == ',') ++q; else break;
+        }
+    }
+}
+#endif
 
 }  // namespace
 
 extern "C" {
 
-int lrl_version(void) { return 1; }
+int lrl_version(void) { return 2; }
 
 const char* lrl_last_error(const LrlContext* ctx) { return ctx ? ctx->err.c_str() : "null context"; }
 
@@ -457,12 +493,44 @@ int lrl_create(int device, LrlContext** out) {
     LrlContext* c = new (std::nothrow) LrlContext();
     if (!c) return LRL_ERR_OUT_OF_MEMORY;
     c->device = device;
-    if (hipSetDevice(device) != hipSuccess || hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess ||
-        hipEventCreate(&c->evStart) != hipSuccess || hipEventCreate(&c->evStop) != hipSuccess) {
-        delete c;
+    c->tuning = defaultTuning();
+    // everything the render path needs besides device memory exists from here on: pinned words the host polls / the device reports
+    // into, and the events (creating events or pinned memory inside a timed loop stalled next to a collective's worker thread)
+    bool ok = hipSetDevice(device) == hipSuccess && hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) == hipSuccess &&
+              hipEventCreate(&c->evStart) == hipSuccess && hipEventCreate(&c->evStop) == hipSuccess &&
+              hipHostMalloc(reinterpret_cast<void**>(&c->aliveHost), LRL_WF_MAX_ITERATIONS * 4 * 2, hipHostMallocDefault) == hipSuccess &&
+              hipHostGetDevicePointer(reinterpret_cast<void**>(&c->aliveHostDev), c->aliveHost, 0) == hipSuccess &&
+              hipHostMalloc(reinterpret_cast<void**>(&c->contHost), LRL_FEEDBACK_ITERS * 32, hipHostMallocDefault) == hipSuccess &&
+              hipHostGetDevicePointer(reinterpret_cast<void**>(&c->contHostDev), c->contHost, 0) == hipSuccess &&
+              hipEventCreateWithFlags(&c->evCont, hipEventDisableTiming) == hipSuccess &&
+              hipEventCreateWithFlags(&c->evLastRender, hipEventDisableTiming) == hipSuccess;
+    for (hipEvent_t& e : c->evIter) ok = ok && hipEventCreateWithFlags(&e, hipEventDisableTiming) == hipSuccess;
+    if (!ok) {
+        (void)lrl_destroy(c);
         return LRL_ERR_DEVICE;
     }
+#ifdef LRL_DIAG
+    tuningFromEnv(c->tuning);      // diagnostic builds (tools/build_variant.sh): knobs from the environment, read once, here
+#endif
     *out = c;
+    return LRL_OK;
+}
+
+int lrl_get_tuning(const LrlContext* c, LrlTuning* out) {
+    if (!c || !out) return LRL_ERR_INVALID_ARG;
+    *out = c->tuning;
+    return LRL_OK;
+}
+
+int lrl_set_tuning(LrlContext* c, const LrlTuning* t) {
+    if (!c || !t) return LRL_ERR_INVALID_ARG;
+    if (t->handoverListLen > LRL_TUNING_LIST_MAX) return fail(c, LRL_ERR_INVALID_ARG, "handoverListLen > LRL_TUNING_LIST_MAX");
+    if (t->groupLanes != 8 && t->groupLanes != 16 && t->groupLanes != 32 && t->groupLanes != 64) return fail(c, LRL_ERR_INVALID_ARG, "groupLanes must be 8, 16, 32 or 64");
+    if (t->groupCapX > 2 || t->compactFrom < -1 || !(t->workLow >= 0.0f)) return fail(c, LRL_ERR_INVALID_ARG, "groupCapX must be 0..2, compactFrom >= -1, workLow >= 0");
+    if (t->contSlots > (1u << 22)) return fail(c, LRL_ERR_LIMIT, "contSlots > 2^22");
+    c->tuning = *t;
+    c->handoverThr.clear();      // the adaptive thresholds start again from the new base values
+    c->feedbackTick = 0;
     return LRL_OK;
 }
 
@@ -477,6 +545,7 @@ int lrl_destroy(LrlContext* c) {
     if (c->aliveHost) (void)hipHostFree(c->aliveHost);
     if (c->contHost) (void)hipHostFree(c->contHost);
     if (c->evCont) (void)hipEventDestroy(c->evCont);
+    if (c->evLastRender) (void)hipEventDestroy(c->evLastRender);
     for (hipEvent_t e : c->evIter) if (e) (void)hipEventDestroy(e);
     if (c->evStart) (void)hipEventDestroy(c->evStart);
     if (c->evStop) (void)hipEventDestroy(c->evStop);
@@ -558,7 +627,7 @@ int lrl_scene_upload(LrlContext* c, const LrlSceneView* s) {
         if (rc) return rc;
         HIP_TRY(c, hipStreamSynchronize(c->stream));
     }
-    if (!deviceBuild && std::getenv("LRL_DEBUG")) std::fprintf(stderr, "lrl: binary nodes %u (depth %u), four-wide tree depth %u\n", s->bvhNodeNum, depth, c->node4Depth);
+    if (!deviceBuild && c->tuning.debug) std::fprintf(stderr, "lrl: binary nodes %u (depth %u), four-wide tree depth %u\n", s->bvhNodeNum, depth, c->node4Depth);
     if (deviceBuild) {
         if ((rc = ensure(c, c->primMin, size_t(primTotal) * 16))) return rc;
         if ((rc = ensure(c, c->primMax, size_t(primTotal) * 16))) return rc;
@@ -642,7 +711,7 @@ int lrl_scene_upload(LrlContext* c, const LrlSceneView* s) {
     HIP_TRY(c, hipStreamSynchronize(c->stream));
     if (deviceBuild) {
         if ((rc = buildOnDevice(c, s, uint32_t(primTotal), recCount, depth))) return rc;
-        if (std::getenv("LRL_DEBUG")) std::fprintf(stderr, "lrl: device-built tree over %llu primitives: %u records, height %u, four-wide height %u\n",
+        if (c->tuning.debug) std::fprintf(stderr, "lrl: device-built tree over %llu primitives: %u records, height %u, four-wide height %u\n",
                                                    (unsigned long long)primTotal, recCount, depth, c->node4Depth);
     }
     c->deviceBuilt = deviceBuild;
@@ -669,6 +738,7 @@ int lrl_scene_read_triangles_gpu(LrlContext* c, uint32_t first, uint32_t count, 
     HIP_TRY(c, hipSetDevice(c->device));
     std::vector<float4> hot(size_t(count) * 4);
     std::vector<LrlTriCold> cold(count);
+    HIP_TRY(c, hipStreamSynchronize(c->stream));      // TrianglePre of an update or a water step may still be in flight (the stream is non-blocking)
     if (count) {
         HIP_TRY(c, hipMemcpy(hot.data(), static_cast<const float4*>(c->triHot.p) + size_t(first) * 4, hot.size() * sizeof(float4), hipMemcpyDeviceToHost));
         HIP_TRY(c, hipMemcpy(cold.data(), static_cast<const LrlTriCold*>(c->triCold.p) + first, cold.size() * sizeof(LrlTriCold), hipMemcpyDeviceToHost));
@@ -693,6 +763,7 @@ int lrl_scene_read_circles(LrlContext* c, uint32_t first, uint32_t count, LrlCir
     if (!c->haveScene) return fail(c, LRL_ERR_NO_SCENE, "no scene uploaded");
     if (uint64_t(first) + count > c->num.circleNum) return fail(c, LRL_ERR_INVALID_ARG, "circle range out of bounds");
     HIP_TRY(c, hipSetDevice(c->device));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));      // CirclePre runs on the context's (non-blocking) stream
     if (count) HIP_TRY(c, hipMemcpy(out, static_cast<const LrlCircle*>(c->circles.p) + first, size_t(count) * sizeof(LrlCircle), hipMemcpyDeviceToHost));
     return LRL_OK;
 }
@@ -733,237 +804,263 @@ int lrl_compute_decay_origin(LrlContext* c, uint32_t variant, LrlDecayOrigin* ou
 
 
 // ---- wavefront pipeline: generate, then (trace, shade) per ray segment until no path is alive ----
-#define LRL_WF_MAX_ITERATIONS 4096u
-#define LRL_FEEDBACK_ITERS 64u
 #define LRL_LIST_KINDS 8u        /* ray kinds (closest + one shadow ray per light) the compacted lists are kept for */
+
+// LrlTuning::debug >= 2: a line on stderr before and after every HIP call of the render path, so that a call that blocks names itself
+#define CRUMB_TRY(c, what, expr)                                                        \
+    do {                                                                                \
+        if ((c)->tuning.debug >= 2) { std::fprintf(stderr, "lrl[%d]: > %s\n", (c)->device, what); std::fflush(stderr); } \
+        HIP_TRY(c, expr);                                                               \
+        if ((c)->tuning.debug >= 2) { std::fprintf(stderr, "lrl[%d]: < %s\n", (c)->device, what); std::fflush(stderr); } \
+    } while (0)
+
+// where the blocks of one pass (bsz samples of Ppix path slots each) sit in the arena; every size grows with bsz, so the layout of a
+// smaller last batch fits the arena of a full one
+struct WfLayout {
+    size_t state, flags, rayQ, maskC, maskS, refr, ovf, alive, contHead, contRefs, rayList, listCount, total;
+};
+static WfLayout wfLayout(size_t P, uint32_t L, uint32_t refrEntries, uint32_t ovfN, uint32_t contSlots, uint32_t contStride, bool special) {
+    WfLayout o{};
+    size_t off = 0;
+    auto take = [&](size_t bytes) { size_t at = off; off += (bytes + 255) / 256 * 256; return at; };
+    const size_t words = P / 64, chunks = words * (1 + size_t(L)) / LRL_WF_CHUNK_WORDS;
+    o.state = take(P * 16 * 6); o.flags = take(P * 4); o.rayQ = take(P * (1 + size_t(L)) * 32);
+    o.maskC = take(words * 8); o.maskS = take(words * 8);
+    o.refr = take(P * 64 * refrEntries); o.ovf = take(chunks * ovfN * 512);
+    o.alive = take(LRL_WF_MAX_ITERATIONS * 4 * 2 + LRL_FEEDBACK_ITERS * LRL_WORK_COUNTERS * 128);
+    o.contHead = take(size_t(contSlots) * 16); o.contRefs = take(size_t(contSlots) * contStride * 4);
+    o.rayList = take(special ? P * (1 + size_t(L)) * 4 : 0);
+    o.listCount = take(special ? size_t(LRL_WF_MAX_ITERATIONS) * LRL_LIST_KINDS * 4 : 0);
+    o.total = off;
+    return o;
+}
+
 static int renderWavefront(LrlContext* c, const LrlRenderParams* p, const KScene& k, KFrame f, float* rgbaDev, uint32_t* hitDev,
                            unsigned long long* ctr, hipStream_t stream, uint32_t rows, hipEvent_t e0, hipEvent_t e1) {
+    const LrlTuning& tn = c->tuning;
     const bool fast = p->mode == LRL_MODE_FAST, pool = p->variant == LRL_VARIANT_POOL;
     const uint32_t L = c->num.pointLightNum;
     const uint32_t tilesX = (c->width + 7) / 8, tilesY = (rows + 7) / 8;
-    const uint64_t P64 = (uint64_t(tilesX) * tilesY * 64 + LRL_WF_SLOT_ALIGN - 1) / LRL_WF_SLOT_ALIGN * LRL_WF_SLOT_ALIGN;
-    if (P64 * (1 + uint64_t(L)) >= (1ull << 31)) return fail(c, LRL_ERR_LIMIT, "pixels x (1 + lights) of one render exceeds 2^31 ray slots: render in row stripes");
-    const size_t P = size_t(P64);
-    const uint32_t words = uint32_t(P / 64), chunks = words * (1 + L) / LRL_WF_CHUNK_WORDS;
+    const uint64_t Ppix64 = (uint64_t(tilesX) * tilesY * 64 + LRL_WF_SLOT_ALIGN - 1) / LRL_WF_SLOT_ALIGN * LRL_WF_SLOT_ALIGN;
+    if (Ppix64 * (1 + uint64_t(L)) >= (1ull << 31)) return fail(c, LRL_ERR_LIMIT, "pixels x (1 + lights) of one render exceeds 2^31 ray slots: render in row stripes");
+    const size_t Ppix = size_t(Ppix64);
+    // samples traced together: one generate / trace / shade pass carries `batch` samples (slot = b * Ppix + pixel slot), so that
+    // the launches of a high-spp frame fill the chip (a 1080p sample is 2 M paths; the chip wants about 8 M rays per launch) and a frame
+    // pays the tails of its launches once per batch instead of once per sample
+    const uint32_t nSamples = f.sampleEnd - f.sampleBegin;
+    const uint64_t batchSlots = tn.batchSlots ? tn.batchSlots : (1u << 23);
+    uint32_t batch = uint32_t(std::min<uint64_t>(nSamples, std::max<uint64_t>(1, batchSlots / Ppix64)));
+    while (batch > 1 && Ppix64 * batch * (1 + uint64_t(L)) >= (1ull << 31)) --batch;
     // Trace kernel per iteration.  PARITY and counting renders: wfTraceKernel (the reference's visit order).  FAST: the lean
     // one-lane-per-ray kernel over the four-wide tree, which hands rays that are still going after handoverTrips trips to the
-    // wave-per-ray kernel.  LRL_TRACE=ref / LRL_HANDOVER*: diagnostics.
-    const char* which = std::getenv("LRL_TRACE");      // "ref": wfTraceKernel in FAST arithmetic
-    const bool special = fast && !ctr && !(which && !std::strcmp(which, "ref"));
+    // lanes-per-ray kernel.
+    const bool special = fast && !ctr && !tn.traceRef;
     // deepest stack: one parked child per level of the binary tree (wfTraceKernel), three per level of the four-wide tree (lean)
     const uint32_t stackNeed = special ? std::max(c->bvhDepth + 1, 3 * c->node4Depth + 4) : c->bvhDepth + 1;
     const uint32_t ldsRows = special ? uint32_t(LRL_LEAN_STACK) : uint32_t(LRL_WF_STACK);
     const uint32_t ovfN = stackNeed > ldsRows ? stackNeed - ldsRows : 0u;
-    const size_t raysAll = P * (1 + size_t(L));
-    const size_t ovfBytes = size_t(chunks) * ovfN * 512;
     const uint32_t refrEntries = c->hasTransmission ? p->maxDepth : 0u;
-    // arena layout (every block 256-B aligned)
-    size_t off = 0;
-    auto take = [&](size_t bytes) { size_t o = off; off += (bytes + 255) / 256 * 256; return o; };
-    const size_t oState = take(P * 16 * 6), oFlags = take(P * 4), oRayQ = take(P * (1 + size_t(L)) * 32), oMaskC = take(size_t(words) * 8),
-                 oMaskS = take(size_t(words) * 8), oRefr = take(P * 64 * refrEntries), oOvf = take(ovfBytes),
-                 oAlive = take(LRL_WF_MAX_ITERATIONS * 4 * 2 + LRL_FEEDBACK_ITERS * LRL_WORK_COUNTERS * 128);
-    const char* slotsEnv = std::getenv("LRL_CONT_SLOTS");
-    const uint32_t contSlots = slotsEnv ? std::max(1024u, uint32_t(std::atoi(slotsEnv))) : 262144u, contStride = stackNeed + 1;
-    const size_t oContHead = take(size_t(contSlots) * 16), oContRefs = take(size_t(contSlots) * contStride * 4);
-    const size_t oRayList = take(special ? P * (1 + size_t(L)) * 4 : 0), oListCount = take(special ? size_t(LRL_WF_MAX_ITERATIONS) * LRL_LIST_KINDS * 4 : 0);
-    int rc = ensure(c, c->wfArena, off);
+    const uint32_t contStride = stackNeed + 1;
+    const uint32_t contSlots = tn.contSlots ? std::max(1024u, tn.contSlots)
+                                            : uint32_t(std::min<uint64_t>(1u << 22, 262144ull * ((Ppix64 * batch + (1u << 21) - 1) >> 21)));
+    const WfLayout full = wfLayout(Ppix * batch, L, refrEntries, ovfN, contSlots, contStride, special);
+    int rc = ensure(c, c->wfArena, full.total);
     if (rc) return rc;
-    if (!c->aliveHost) {
-        HIP_TRY(c, hipHostMalloc(reinterpret_cast<void**>(&c->aliveHost), LRL_WF_MAX_ITERATIONS * 4 * 2, hipHostMallocDefault));
-        HIP_TRY(c, hipHostGetDevicePointer(reinterpret_cast<void**>(&c->aliveHostDev), c->aliveHost, 0));
-        for (hipEvent_t& e : c->evIter) HIP_TRY(c, hipEventCreateWithFlags(&e, hipEventDisableTiming));
-        HIP_TRY(c, hipHostMalloc(reinterpret_cast<void**>(&c->contHost), LRL_FEEDBACK_ITERS * 4 + LRL_FEEDBACK_ITERS * LRL_WORK_COUNTERS * 128, hipHostMallocDefault));
-        HIP_TRY(c, hipEventCreateWithFlags(&c->evCont, hipEventDisableTiming));
-    }
-    char* base = static_cast<char*>(c->wfArena.p);
-    WFrame wf{};
-    wf.P = uint32_t(P); wf.words = words; wf.tilesX = tilesX; wf.tilesY = tilesY; wf.overflowEntries = ovfN;
-    float4* st = reinterpret_cast<float4*>(base + oState);
-    wf.answer = st; wf.ratio = st + P; wf.decay = st + 2 * P; wf.hit = st + 3 * P;
-    wf.pendA = st + 4 * P; wf.pendB = st + 5 * P;
-    wf.flags = reinterpret_cast<uint32_t*>(base + oFlags);
-    wf.rayQ = reinterpret_cast<float4*>(base + oRayQ);
-    wf.maskC = reinterpret_cast<unsigned long long*>(base + oMaskC);
-    wf.maskS = reinterpret_cast<unsigned long long*>(base + oMaskS);
-    wf.refr = refrEntries ? reinterpret_cast<float4*>(base + oRefr) : nullptr;
-    wf.overflow = reinterpret_cast<uint2*>(base + oOvf);
-    wf.alive = reinterpret_cast<uint32_t*>(base + oAlive);
-    uint32_t* const contCounts = wf.alive + LRL_WF_MAX_ITERATIONS;      // one per iteration, zeroed with `alive`
-    uint32_t* const contWorkAll = contCounts + LRL_WF_MAX_ITERATIONS;   // [iteration < LRL_FEEDBACK_ITERS][LRL_WORK_COUNTERS] 128 B apart, zeroed with `alive`
-    const char* ho = std::getenv("LRL_HANDOVER");
-    const char* hoLate = std::getenv("LRL_HANDOVER_LATE");
-    const uint32_t handoverEarly = ho ? uint32_t(std::atoi(ho)) : 48u, handoverLate = hoLate ? uint32_t(std::atoi(hoLate)) : 16u;
+    char* const base = static_cast<char*>(c->wfArena.p);
+    const uint32_t handoverEarly = tn.handoverEarly, handoverLate = tn.handoverLate;
     // The hand-over pays for rays with much work left.  Where most rays are of middling length (Pool: flat tree of tall
     // boxes) the slots run out, or the rays that leave are nearly done and cost more to move than to finish, so the
-    // threshold of an iteration follows what that iteration did in the last finished sample: doubled (x4 when far beyond
-    // the slots) while (nearly) all slots were asked for or the handed-over rays needed fewer than LRL_WORK_LOW frontier
+    // threshold of an iteration follows what that iteration did in an earlier pass: doubled (x4 when far beyond
+    // the slots) while (nearly) all slots were asked for or the handed-over rays needed fewer than workLow frontier
     // entries each.  A ratchet: thresholds that came back down made the Pool oscillate between two states from sample to
-    // sample (160 ms a frame against 150 for any pinned state); a new scene starts from the defaults.  LRL_ADAPT=0 pins them.
+    // sample (160 ms a frame against 150 for any pinned state); a new scene starts from the defaults.  adapt = 0 pins them.
     // lanes per handed-over ray: groups of 16 when a group's share of the frontier holds the hand-over plus a depth-first
     // descent (lrl_lean.inc), else a wave per ray
-    const char* groupEnv = std::getenv("LRL_SWARM_GROUP");
-    uint32_t swarmGroup = groupEnv ? uint32_t(std::atoi(groupEnv)) : 16u;
+    uint32_t swarmGroup = tn.groupLanes;
     if (swarmGroup != 8 && swarmGroup != 16 && swarmGroup != 32) swarmGroup = 64;
     // a ray's frontier: LRL_GROUP_CAP entries, twice that where the hand-over record + depth-first reserve (contStride) would
-    // leave less than 2/5 of it for full rounds (LRL_GROUP_CAP_X: 1 or 2 times; groups of 16 lanes only)
-    const char* capEnv = std::getenv("LRL_GROUP_CAP_X");
-    const uint32_t groupCap = LRL_GROUP_CAP * ((swarmGroup == 16 && (capEnv ? std::atoi(capEnv) >= 2 : 2 * contStride + 3 * swarmGroup > LRL_GROUP_CAP - 32)) ? 2u : 1u);      // C2 (stride 77): 256 is 1.3 % faster; 100 M device-built tree (95): 512 is 1.85x faster on C5
+    // leave less than 2/5 of it for full rounds (groups of 16 lanes only)
+    const uint32_t groupCap = LRL_GROUP_CAP * ((swarmGroup == 16 && (tn.groupCapX ? tn.groupCapX >= 2 : 2 * contStride + 3 * swarmGroup > LRL_GROUP_CAP - 32)) ? 2u : 1u);      // C2 (stride 77): 256 is 1.3 % faster; 100 M device-built tree (95): 512 is 1.85x faster on C5
     if (swarmGroup != 64 && 2 * contStride + 3 * swarmGroup > groupCap) swarmGroup = 64;
     const bool handoverFits = 2 * contStride + 192 <= LRL_SWARM_CAP;      // else (trees hundreds of levels deep) the lean kernel finishes every ray itself
-    const char* sparseEnv = std::getenv("LRL_SPARSE_FROM");      // first iteration traced with the larger workgroups
-    const uint32_t sparseFrom = sparseEnv ? uint32_t(std::atoi(sparseEnv)) : 5u;      // (measured: C2 best with none of its 5, C1 with 8 of its 56, C3 with 4 of its 10)
-    const bool adapt = !(std::getenv("LRL_ADAPT") && std::atoi(std::getenv("LRL_ADAPT")) == 0);
-    std::vector<uint32_t> thrList;                               // LRL_HANDOVER_LIST=a,b,c,...: one threshold per iteration (the last repeats)
-    if (const char* tl = std::getenv("LRL_HANDOVER_LIST")) for (const char* q = tl; *q;) { thrList.push_back(uint32_t(std::strtoul(q, const_cast<char**>(&q), 10))); if (*q == ',') ++q; else break; }
-    auto baseThr = [&](uint32_t i) { return !thrList.empty() ? thrList[std::min<size_t>(i, thrList.size() - 1)] : i < 2 ? handoverEarly : i == 2 ? (handoverEarly + handoverLate) / 2 : handoverLate; };   // few rays left after the first bounces: the waves are free sooner (C2: a plateau around 48,48,32,16,16)
-    if (c->handoverThr.empty() || (!adapt && c->handoverThr[0] != baseThr(0))) {
+    const uint32_t sparseFrom = tn.sparseFrom;      // (measured: C2 best with none of its 5, C1 with 8 of its 56, C3 with 4 of its 10)
+    const bool adapt = tn.adapt != 0;
+    auto baseThr = [&](uint32_t i) { return tn.handoverListLen ? tn.handoverList[std::min<uint32_t>(i, tn.handoverListLen - 1)] : i < 2 ? handoverEarly : i == 2 ? (handoverEarly + handoverLate) / 2 : handoverLate; };   // few rays left after the first bounces: the waves are free sooner (C2: a plateau around 48,48,32,16,16)
+    if (c->handoverThr.empty()) {
         c->handoverThr.resize(LRL_FEEDBACK_ITERS);
         for (uint32_t i = 0; i < LRL_FEEDBACK_ITERS; ++i) c->handoverThr[i] = baseThr(i);
         c->swarmGrid.assign(LRL_FEEDBACK_ITERS, contSlots);
     }
-    const char* wl = std::getenv("LRL_WORK_LOW");
-    const float workLow = wl ? float(std::atof(wl)) : 12.0f;
+    const float workLow = tn.workLow;
     c->workPerRay.resize(LRL_FEEDBACK_ITERS, 0.0f);
+    // The counters of a pass reach the host without a copy: the shade kernel's first block stores them into pinned memory
+    // (WFrame::feedbackHost) and an event recorded behind the pass says when they are all there.  (Round 1 copied them with
+    // hipMemcpyAsync on the caller's stream; a device-to-host copy is the one call of the render path that may wait for the
+    // stream to drain inside the runtime, and a caller's stream may itself be waiting for a collective.)
     auto feedback = [&]() {
         if (!c->contIters || hipEventQuery(c->evCont) != hipSuccess) return;
+        const uint32_t slotsThen = c->contSlotsInFlight;
         for (uint32_t i = 0; i < c->contIters; ++i) {
             uint32_t& t = c->handoverThr[i];
-            const uint32_t asked = c->contHost[i];
+            const volatile uint32_t* h = c->contHost + size_t(i) * 8;
+            const uint32_t asked = h[0];
             if (t == 0) continue;
             uint64_t work = 0;
-            for (uint32_t w = 0; w < LRL_WORK_COUNTERS; ++w) work += c->contHost[LRL_FEEDBACK_ITERS + (size_t(i) * LRL_WORK_COUNTERS + w) * 32];
-            const uint32_t served = std::min(asked, contSlots);
+            for (uint32_t w = 0; w < LRL_WORK_COUNTERS; ++w) work += h[1 + w];
+            const uint32_t served = std::min(asked, slotsThen);
             const float perRay = served ? 16.0f * float(work) / float(served) : 0.0f;       // one wave in 16 reports
             c->workPerRay[i] = perRay;
             // rays that were nearly done when they left (a few frontier entries each) cost more to hand over than to finish
             // where they were: Pool's rays are all of middling length; the mesh scenes' long rays need 30-40 entries
             if (!adapt) {}
             else if (served >= 1024 && perRay < workLow) t = std::min(t * 2, 4096u);
-            else if (asked > 4 * contSlots) t = std::min(t * 4, 4096u);
-            else if (asked > contSlots / 16 * 15) t = std::min(t * 2, 4096u);
+            else if (asked > 4 * uint64_t(slotsThen)) t = std::min(t * 4, 4096u);
+            else if (asked > slotsThen / 16 * 15) t = std::min(t * 2, 4096u);
             // dispatching 65536 workgroups that find nothing costs ~15 us a launch: twice what was asked for last time is
             // plenty (the kernel strides over the slots whatever the grid)
-            c->swarmGrid[i] = std::min(contSlots, std::max(2048u, (2 * asked + 1023u) / 1024u * 1024u));
+            c->swarmGrid[i] = std::max(2048u, uint32_t(std::min<uint64_t>(1u << 22, (2ull * asked + 1023u) / 1024u * 1024u)));
         }
         c->contIters = 0;
     };
-    wf.handoverTrips = handoverEarly;
-    wf.contSlots = contSlots; wf.contStride = contStride; wf.groupCap = groupCap;
-    wf.contHead = reinterpret_cast<uint4*>(base + oContHead);
-    wf.contRefs = reinterpret_cast<uint32_t*>(base + oContRefs);
-    wf.contCount = contCounts;
-    wf.rayList = reinterpret_cast<uint32_t*>(base + oRayList);
-    uint32_t* const listCounts = reinterpret_cast<uint32_t*>(base + oListCount);      // [iteration][LRL_LIST_KINDS]
-    wf.listCount = listCounts;
-    // compaction of the live rays before the trace launches of the late segments (LRL_COMPACT_FROM: first such iteration,
+    // compaction of the live rays before the trace launches of the late segments (compactFrom: first such iteration,
     // 0 = never).  It pays where the survivors are scattered over the mask words or a trip is expensive: after diffuse
     // bounces (C2 with them: 2.07 -> 1.60 ms) and on scenes far beyond the caches (100 M triangles: 2.84 -> 2.62 ms; C5:
     // 141.5 -> 132.6 ms); on C2 itself, the Pool and the default scene the extra kernel per iteration costs 1.5-10 %.
     // With more kinds of rays than LRL_LIST_KINDS (lights + 1) the masks are used throughout.
-    const char* cfEnv = std::getenv("LRL_COMPACT_FROM");
-    const uint32_t compactFrom = (1 + L > LRL_LIST_KINDS) ? 0u : cfEnv ? uint32_t(std::atoi(cfEnv))
+    const uint32_t compactFrom = (1 + L > LRL_LIST_KINDS) ? 0u : tn.compactFrom >= 0 ? uint32_t(tn.compactFrom)
                                  : (f.diffuse || size_t(c->recNum) * 64 > (size_t(1) << 30)) ? 2u : 0u;
-    wf.out = reinterpret_cast<float4*>(rgbaDev);
-    wf.hitOut = reinterpret_cast<uint2*>(hitDev);
-    wf.counters = ctr;
-    wf.timeline = nullptr;
-    const char* tlPath = std::getenv("LRL_TIMELINE");          // diagnostic builds (LRL_DIAG): timeline of ONE trace launch
+#ifdef LRL_DIAG
+    const char* tlPath = std::getenv("LRL_TIMELINE");          // diagnostic builds only: timeline of ONE trace launch
     const char* tlIter = std::getenv("LRL_TIMELINE_ITER");
     const uint32_t tlWanted = tlIter ? uint32_t(std::atoi(tlIter)) : 0u;
-    const size_t tlEntries = std::max<size_t>(raysAll / 16, 131072u + 65536u);      // lean: one per mask word; wave-per-ray: 131072 + slot
+    const size_t tlEntries = std::max<size_t>(Ppix * batch * (1 + size_t(L)) / 16, 131072u + 65536u);      // lean: one per mask word; wave-per-ray: 131072 + slot
     if (tlPath && *tlPath && (rc = ensure(c, c->timelineDev, tlEntries * 48))) return rc;
+#endif
     // every path ends after at most 2^(maxDepth+1) segments (each hit continues one reflection and parks one refraction)
     // (without a transmitting material nothing is ever parked: a path is primary + at most maxDepth reflections, and its
     // last segment casts no shadow rays, so iteration maxDepth finalises whatever is left)
     const uint32_t bound = c->hasTransmission ? uint32_t(std::min<uint64_t>(LRL_WF_MAX_ITERATIONS, (2ull << p->maxDepth) + 2)) : p->maxDepth + 1;
     const bool perKernel = c->timing && (p->flags & LRL_FLAG_TIME_KERNELS);
-    auto timedTrace = [&](uint32_t iter) -> int {
-        hipEvent_t a = nullptr, b = nullptr;
-        if (perKernel && c->timingUsed < LRL_MAX_TIMED_LAUNCHES) {
-            if (c->timingUsed == c->timingEvents.size()) {
-                HIP_TRY(c, hipEventCreate(&a));
-                HIP_TRY(c, hipEventCreate(&b));
-                c->timingEvents.emplace_back(a, b);
-            }
-            a = c->timingEvents[c->timingUsed].first; b = c->timingEvents[c->timingUsed].second;
-            ++c->timingUsed;
-            HIP_TRY(c, hipEventRecord(a, stream));
-        }
-        if (special) {
-            wf.contCount = contCounts + (iter < LRL_WF_MAX_ITERATIONS ? iter : 0);
-            wf.handoverTrips = handoverFits ? c->handoverThr[std::min(iter, LRL_FEEDBACK_ITERS - 1)] : 0u;
-            wf.contWork = contWorkAll + size_t(std::min(iter, LRL_FEEDBACK_ITERS - 1)) * LRL_WORK_COUNTERS * 32;
-            const bool compact = compactFrom != 0 && iter >= compactFrom && iter < LRL_WF_MAX_ITERATIONS;
-            wf.listCount = listCounts + size_t(iter < LRL_WF_MAX_ITERATIONS ? iter : 0) * LRL_LIST_KINDS;
-            HIP_TRY(c, lrl_fast::wfLaunchTraceLean(k, wf, iter >= sparseFrom, compact, stream));
-            if (wf.handoverTrips) HIP_TRY(c, lrl_fast::wfLaunchTraceSwarm(k, wf, c->swarmGrid[std::min(iter, LRL_FEEDBACK_ITERS - 1)], swarmGroup, stream));
-        }
-        else HIP_TRY(c, fast ? lrl_fast::wfLaunchTrace(k, wf, stream) : lrl_parity::wfLaunchTrace(k, wf, stream));
-        if (b) HIP_TRY(c, hipEventRecord(b, stream));
-        return LRL_OK;
-    };
-    auto dumpTimeline = [&]() -> int {
-        std::vector<unsigned long long> h(tlEntries * 6);
-        HIP_TRY(c, hipStreamSynchronize(stream));
-        HIP_TRY(c, hipMemcpy(h.data(), c->timelineDev.p, h.size() * 8, hipMemcpyDeviceToHost));
-        if (FILE* fp = std::fopen(tlPath, "wb")) { std::fwrite(h.data(), 8, h.size(), fp); std::fclose(fp); }
-        return LRL_OK;
-    };
-    const char* lagEnv = std::getenv("LRL_POLL_LAG");
-    const uint32_t pollLag = lagEnv ? std::min(3u, std::max(1u, uint32_t(std::atoi(lagEnv)))) : 1u;
+    const uint32_t pollLag = std::min(3u, std::max(1u, tn.pollLag));
     const bool poll = c->hasTransmission;    // refraction stacks make the number of segments data dependent
-    if (e0) HIP_TRY(c, hipEventRecord(e0, stream));
-    uint32_t iterations = 0;
-    for (uint32_t s = f.sampleBegin; s < f.sampleEnd; ++s) {
-        wf.sample = s;
+    if (e0) CRUMB_TRY(c, "hipEventRecord(frame start)", hipEventRecord(e0, stream));
+    uint32_t iterations = 0, passIndex = 0;
+    for (uint32_t s = f.sampleBegin; s < f.sampleEnd; ++passIndex) {
+        const uint32_t bsz = std::min(batch, f.sampleEnd - s);
+        const size_t P = Ppix * bsz;
+        const uint32_t words = uint32_t(P / 64);
+        const WfLayout lay = wfLayout(P, L, refrEntries, ovfN, contSlots, contStride, special);
+        WFrame wf{};
+        wf.P = uint32_t(P); wf.words = words; wf.tilesX = tilesX; wf.tilesY = tilesY; wf.overflowEntries = ovfN;
+        wf.sample = s; wf.batch = bsz; wf.Ppix = uint32_t(Ppix); wf.blocksPerSample = uint32_t(Ppix / 256);
+        float4* st = reinterpret_cast<float4*>(base + lay.state);
+        wf.answer = st; wf.ratio = st + P; wf.decay = st + 2 * P; wf.hit = st + 3 * P;
+        wf.pendA = st + 4 * P; wf.pendB = st + 5 * P;
+        wf.flags = reinterpret_cast<uint32_t*>(base + lay.flags);
+        wf.rayQ = reinterpret_cast<float4*>(base + lay.rayQ);
+        wf.maskC = reinterpret_cast<unsigned long long*>(base + lay.maskC);
+        wf.maskS = reinterpret_cast<unsigned long long*>(base + lay.maskS);
+        wf.refr = refrEntries ? reinterpret_cast<float4*>(base + lay.refr) : nullptr;
+        wf.overflow = reinterpret_cast<uint2*>(base + lay.ovf);
+        wf.alive = reinterpret_cast<uint32_t*>(base + lay.alive);
+        uint32_t* const contCounts = wf.alive + LRL_WF_MAX_ITERATIONS;      // one per iteration, zeroed with `alive`
+        uint32_t* const contWorkAll = contCounts + LRL_WF_MAX_ITERATIONS;   // [iteration < LRL_FEEDBACK_ITERS][LRL_WORK_COUNTERS] 128 B apart, zeroed with `alive`
+        wf.handoverTrips = handoverEarly;
+        wf.contSlots = contSlots; wf.contStride = contStride; wf.groupCap = groupCap;
+        wf.contHead = reinterpret_cast<uint4*>(base + lay.contHead);
+        wf.contRefs = reinterpret_cast<uint32_t*>(base + lay.contRefs);
+        wf.contCount = contCounts;
+        wf.contWork = contWorkAll;
+        wf.rayList = reinterpret_cast<uint32_t*>(base + lay.rayList);
+        uint32_t* const listCounts = reinterpret_cast<uint32_t*>(base + lay.listCount);      // [iteration][LRL_LIST_KINDS]
+        wf.listCount = listCounts;
+        wf.out = reinterpret_cast<float4*>(rgbaDev);
+        wf.hitOut = reinterpret_cast<uint2*>(hitDev);
+        wf.counters = ctr;
+        wf.timeline = nullptr;
         if (special) feedback();
+        // the feedback need not be fresh: the first passes after a scene upload, then one pass in eight (and never two in flight)
+        const bool report = special && c->contIters == 0 && (c->feedbackTick++ < 8 || (c->feedbackTick & 7u) == 0);
+        wf.feedbackHost = report ? c->contHostDev : nullptr;
+        if (report) std::memset(c->contHost, 0, size_t(LRL_FEEDBACK_ITERS) * 32);
         // one fill (a size that is no multiple of 16 B costs a second fill kernel): alive, hand-over counts, work counters
-        HIP_TRY(c, hipMemsetAsync(wf.alive, 0, special ? size_t(LRL_WF_MAX_ITERATIONS) * 8 + size_t(LRL_FEEDBACK_ITERS) * LRL_WORK_COUNTERS * 128
-                                                       : size_t(LRL_WF_MAX_ITERATIONS) * 4, stream));
+        CRUMB_TRY(c, "hipMemsetAsync(alive, counters)", hipMemsetAsync(wf.alive, 0, special ? size_t(LRL_WF_MAX_ITERATIONS) * 8 + size_t(LRL_FEEDBACK_ITERS) * LRL_WORK_COUNTERS * 128
+                                                                                            : size_t(LRL_WF_MAX_ITERATIONS) * 4, stream));
         if (special && compactFrom != 0 && bound > compactFrom)
-            HIP_TRY(c, hipMemsetAsync(listCounts, 0, size_t(bound) * LRL_LIST_KINDS * 4, stream));
-        // polled words: the half of the pinned array that sample s - 2 used (the host has seen that sample end)
-        uint32_t* const aliveWords = c->aliveHost + size_t(s & 1u) * LRL_WF_MAX_ITERATIONS;
-        wf.aliveHost = poll ? c->aliveHostDev + size_t(s & 1u) * LRL_WF_MAX_ITERATIONS : nullptr;
+            CRUMB_TRY(c, "hipMemsetAsync(list counts)", hipMemsetAsync(listCounts, 0, size_t(bound) * LRL_LIST_KINDS * 4, stream));
+        // polled words: the half of the pinned array that pass - 2 used (the host has seen that pass end)
+        uint32_t* const aliveWords = c->aliveHost + size_t(passIndex & 1u) * LRL_WF_MAX_ITERATIONS;
+        wf.aliveHost = poll ? c->aliveHostDev + size_t(passIndex & 1u) * LRL_WF_MAX_ITERATIONS : nullptr;
         if (poll) std::memset(aliveWords, 0, size_t(bound) * 4);
-        HIP_TRY(c, fast ? lrl_fast::wfLaunchGenerate(k, f, wf, stream) : lrl_parity::wfLaunchGenerate(k, f, wf, stream));
+        CRUMB_TRY(c, "generate", fast ? lrl_fast::wfLaunchGenerate(k, f, wf, stream) : lrl_parity::wfLaunchGenerate(k, f, wf, stream));
         uint32_t iter = 0;
         for (; iter < bound; ++iter) {
+#ifdef LRL_DIAG
             const bool tl = tlPath && *tlPath && iter == tlWanted && s == f.sampleBegin;
             if (tl) { HIP_TRY(c, hipMemsetAsync(c->timelineDev.p, 0, tlEntries * 48, stream)); wf.timeline = static_cast<unsigned long long*>(c->timelineDev.p); }
-            if ((rc = timedTrace(iter))) return rc;
-            if (tl) { wf.timeline = nullptr; if ((rc = dumpTimeline())) return rc; }
-            HIP_TRY(c, fast ? lrl_fast::wfLaunchShade(k, f, wf, iter, pool, stream) : lrl_parity::wfLaunchShade(k, f, wf, iter, pool, stream));
+#endif
+            hipEvent_t ta = nullptr, tb = nullptr;
+            if (perKernel && c->timingUsed < LRL_MAX_TIMED_LAUNCHES) {
+                if (c->timingUsed == c->timingEvents.size()) {
+                    HIP_TRY(c, hipEventCreate(&ta));
+                    HIP_TRY(c, hipEventCreate(&tb));
+                    c->timingEvents.emplace_back(ta, tb);
+                }
+                ta = c->timingEvents[c->timingUsed].first; tb = c->timingEvents[c->timingUsed].second;
+                ++c->timingUsed;
+                HIP_TRY(c, hipEventRecord(ta, stream));
+            }
+            if (special) {
+                const uint32_t fi = std::min(iter, LRL_FEEDBACK_ITERS - 1);
+                wf.contCount = contCounts + (iter < LRL_WF_MAX_ITERATIONS ? iter : 0);
+                wf.handoverTrips = handoverFits ? c->handoverThr[fi] : 0u;
+                wf.contWork = contWorkAll + size_t(fi) * LRL_WORK_COUNTERS * 32;
+                const bool compact = compactFrom != 0 && iter >= compactFrom && iter < LRL_WF_MAX_ITERATIONS;
+                wf.listCount = listCounts + size_t(iter < LRL_WF_MAX_ITERATIONS ? iter : 0) * LRL_LIST_KINDS;
+                CRUMB_TRY(c, "trace (lean)", lrl_fast::wfLaunchTraceLean(k, wf, iter >= sparseFrom, compact, stream));
+                if (wf.handoverTrips) CRUMB_TRY(c, "trace (hand-over)", lrl_fast::wfLaunchTraceSwarm(k, wf, std::min(contSlots, c->swarmGrid[fi]), swarmGroup, stream));
+            }
+            else CRUMB_TRY(c, "trace", fast ? lrl_fast::wfLaunchTrace(k, wf, stream) : lrl_parity::wfLaunchTrace(k, wf, stream));
+            if (tb) HIP_TRY(c, hipEventRecord(tb, stream));
+#ifdef LRL_DIAG
+            if (tl) {
+                wf.timeline = nullptr;
+                std::vector<unsigned long long> h(tlEntries * 6);
+                HIP_TRY(c, hipStreamSynchronize(stream));
+                HIP_TRY(c, hipMemcpy(h.data(), c->timelineDev.p, h.size() * 8, hipMemcpyDeviceToHost));
+                if (FILE* fp = std::fopen(tlPath, "wb")) { std::fwrite(h.data(), 8, h.size(), fp); std::fclose(fp); }
+            }
+#endif
+            CRUMB_TRY(c, "shade", fast ? lrl_fast::wfLaunchShade(k, f, wf, iter, pool, stream) : lrl_parity::wfLaunchShade(k, f, wf, iter, pool, stream));
             if (!poll) continue;   // exact bound: nothing to ask the device, the whole frame is enqueued without a host wait
-            HIP_TRY(c, hipEventRecord(c->evIter[iter & 3], stream));
+            CRUMB_TRY(c, "hipEventRecord(iteration)", hipEventRecord(c->evIter[iter & 3], stream));
             if (iter >= pollLag) {      // look at an earlier iteration while this one runs: the pipeline ends pollLag (empty) iterations late
-                HIP_TRY(c, hipEventSynchronize(c->evIter[(iter - pollLag) & 3]));
+                CRUMB_TRY(c, "hipEventSynchronize(iteration)", hipEventSynchronize(c->evIter[(iter - pollLag) & 3]));
                 if (reinterpret_cast<volatile uint32_t*>(aliveWords)[iter - pollLag] == 0) { ++iter; break; }
             }
         }
         if (poll && iter == bound) {      // the last iteration has not been looked at yet
-            HIP_TRY(c, hipEventSynchronize(c->evIter[(bound - 1) & 3]));
+            CRUMB_TRY(c, "hipEventSynchronize(last iteration)", hipEventSynchronize(c->evIter[(bound - 1) & 3]));
             if (reinterpret_cast<volatile uint32_t*>(aliveWords)[bound - 1] != 0) return fail(c, LRL_ERR_LIMIT, "wavefront pipeline did not finish within its iteration bound");
         }
+        if (bsz > 1) CRUMB_TRY(c, "accumulate", fast ? lrl_fast::wfLaunchAccumulate(f, wf, stream) : lrl_parity::wfLaunchAccumulate(f, wf, stream));
         iterations += iter;
-        // the feedback need not be fresh: the first samples after a scene upload, then one sample in eight (two copy kernels each)
-        if (special && c->contIters == 0 && (c->feedbackTick++ < 8 || (c->feedbackTick & 7u) == 0)) {      // (a copy still in flight is left alone)
+        if (report) {
             c->contIters = std::min(iter, LRL_FEEDBACK_ITERS);
-            HIP_TRY(c, hipMemcpyAsync(c->contHost, contCounts, size_t(c->contIters) * 4, hipMemcpyDeviceToHost, stream));
-            HIP_TRY(c, hipMemcpyAsync(c->contHost + LRL_FEEDBACK_ITERS, contWorkAll, size_t(c->contIters) * LRL_WORK_COUNTERS * 128, hipMemcpyDeviceToHost, stream));
-            HIP_TRY(c, hipEventRecord(c->evCont, stream));
+            c->contSlotsInFlight = contSlots;
+            CRUMB_TRY(c, "hipEventRecord(feedback)", hipEventRecord(c->evCont, stream));
         }
-        if (std::getenv("LRL_DEBUG") && special) {
+        if (tn.debug && special) {
             std::vector<uint32_t> cc(iter);
             HIP_TRY(c, hipStreamSynchronize(stream));
             HIP_TRY(c, hipMemcpy(cc.data(), contCounts, iter * 4, hipMemcpyDeviceToHost));
-            std::fprintf(stderr, "lrl: handed-over rays per iteration (threshold, entries per ray at the last feedback):");
+            std::fprintf(stderr, "lrl: samples %u..%u, handed-over rays per iteration (threshold, entries per ray at the last feedback):", s, s + bsz);
             for (uint32_t i = 0; i < iter; ++i) std::fprintf(stderr, " %u (%u, %.0f)", cc[i], c->handoverThr[std::min(i, LRL_FEEDBACK_ITERS - 1)], c->workPerRay[std::min(i, LRL_FEEDBACK_ITERS - 1)]);
-            std::fprintf(stderr, "  [%u lanes per handed-over ray, stride %u]\n", swarmGroup, contStride);
+            std::fprintf(stderr, "  [%u lanes per handed-over ray, stride %u, %u slots]\n", swarmGroup, contStride, contSlots);
         }
+        s += bsz;
     }
-    if (e1) HIP_TRY(c, hipEventRecord(e1, stream));
+    if (e1) CRUMB_TRY(c, "hipEventRecord(frame end)", hipEventRecord(e1, stream));
     c->lastIterations = iterations;
     return LRL_OK;
 }
@@ -983,6 +1080,9 @@ static int renderImpl(LrlContext* c, const LrlRenderParams* p, float* rgbaDev, u
         }
     }
     int rc = LRL_OK;
+    // one arena, one set of per-sample cameras and of polled words per context: a render on another stream than the last one
+    // waits (on the device) for that one to end
+    if (c->renderedOnce && stream != c->lastRenderStream) CRUMB_TRY(c, "hipStreamWaitEvent(last render)", hipStreamWaitEvent(stream, c->evLastRender, 0));
     // the per-sample cameras go to the device only when they changed: an unchanged camera costs no copy and no host wait,
     // so consecutive frames queue back to back
     if (c->transUploaded.size() != tr.size() || std::memcmp(c->transUploaded.data(), tr.data(), tr.size() * sizeof(LrlTrans)) != 0) {
@@ -1012,9 +1112,13 @@ static int renderImpl(LrlContext* c, const LrlRenderParams* p, float* rgbaDev, u
     f.timeline = nullptr;
     f.diffuse = (p->flags & LRL_FLAG_DIFFUSE_BOUNCE) ? 1u : 0u;
     if (f.diffuse && (p->flags & LRL_FLAG_MEGAKERNEL)) return fail(c, LRL_ERR_INVALID_ARG, "LRL_FLAG_DIFFUSE_BOUNCE is implemented in the wavefront pipeline only");
-    const char* tlPath = std::getenv("LRL_TIMELINE");   // diagnostic: per-wave start/end ticks of this launch, dumped to the named file
+#ifdef LRL_DIAG
+    const char* tlPath = std::getenv("LRL_TIMELINE");   // diagnostic builds: per-wave start/end ticks of this launch, dumped to the named file
+#else
+    const char* tlPath = nullptr;
+#endif
     size_t tlWaves = 0;
-    if (tlPath && *tlPath) {
+    if (tlPath && *tlPath && (p->flags & LRL_FLAG_MEGAKERNEL)) {
         uint32_t tx = (c->width + LRL_TILE - 1) / LRL_TILE, ty = (rows + LRL_TILE - 1) / LRL_TILE;
         tlWaves = size_t(tx) * ty * (LRL_BLOCK_THREADS / 64);
         if ((rc = ensure(c, c->timelineDev, tlWaves * 8 * LRL_TIMELINE_WORDS))) return rc;
@@ -1034,10 +1138,16 @@ static int renderImpl(LrlContext* c, const LrlRenderParams* p, float* rgbaDev, u
         e0 = c->timingEvents[c->timingUsed].first; e1 = c->timingEvents[c->timingUsed].second;
         ++c->timingUsed;
     }
+    auto finish = [&]() -> int {
+        CRUMB_TRY(c, "hipEventRecord(last render)", hipEventRecord(c->evLastRender, stream));
+        c->lastRenderStream = stream;
+        c->renderedOnce = true;
+        return LRL_OK;
+    };
     if (!mega) {
         if ((rc = renderWavefront(c, p, k, f, rgbaDev, hitDev, ctr, stream, rows, e0, e1))) return rc;
         c->timed = (e0 == c->evStart);
-        return LRL_OK;
+        return finish();
     }
     HIP_TRY(c, hipEventRecord(e0, stream));
     if (p->mode == LRL_MODE_FAST)
@@ -1052,7 +1162,7 @@ static int renderImpl(LrlContext* c, const LrlRenderParams* p, float* rgbaDev, u
         HIP_TRY(c, hipMemcpy(h.data(), c->timelineDev.p, tlWaves * 8 * LRL_TIMELINE_WORDS, hipMemcpyDeviceToHost));
         if (FILE* fp = std::fopen(tlPath, "wb")) { std::fwrite(h.data(), 8, h.size(), fp); std::fclose(fp); }
     }
-    return LRL_OK;
+    return finish();
 }
 
 static int checkRender(LrlContext* c, const LrlRenderParams* p, uint32_t& rows) {

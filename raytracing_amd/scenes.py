@@ -1,7 +1,7 @@
 """Scene fixtures shared by tests, bench.py and tools: thin Python drivers over the C++ host
 library (raytracing_amd/host/lrl/Scenes.hpp) plus the location of the committed data assets.
 
-Assets under tests/golden/assets/ are DATA taken from the reference's resources by
+Assets under assets/ (repo root) are DATA taken from the reference's resources by
 tools/make_golden.py (small binary STL files; the `room` cube map box-filtered to 128^2; the
 Stanford bunny as a de-duplicated vertex/index table).  No reference source text is stored.
 """
@@ -14,7 +14,7 @@ import numpy as np
 from . import host
 
 REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-ASSETS = os.path.join(REPO, "tests", "golden", "assets")
+ASSETS = os.path.join(REPO, "assets")
 BVH_RESOURCES = os.path.join(ASSETS, "bvh_resources")
 POOL_RESOURCES = os.path.join(ASSETS, "pool_resources")
 BUNNY = os.path.join(ASSETS, "bunny_indexed.npz")

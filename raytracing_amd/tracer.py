@@ -19,7 +19,7 @@ EXPORTS = [
     "lrl_create", "lrl_destroy", "lrl_last_error", "lrl_version", "lrl_scene_upload", "lrl_scene_update_triangles",
     "lrl_scene_read_triangles_gpu", "lrl_scene_read_circles", "lrl_set_camera", "lrl_set_decay_origin", "lrl_compute_decay_origin",
     "lrl_render", "lrl_render_async", "lrl_sync", "lrl_get_counters", "lrl_last_kernel_ms", "lrl_scene_device_bytes",
-    "lrl_timing_begin", "lrl_timing_end", "lrl_water_init", "lrl_water_step", "lrl_water_read", "lrl_scene_rebuild_bvh", "lrl_quantize_rgba8",
+    "lrl_timing_begin", "lrl_timing_end", "lrl_water_init", "lrl_water_step", "lrl_water_read", "lrl_scene_rebuild_bvh", "lrl_quantize_rgba8", "lrl_get_tuning", "lrl_set_tuning",
 ]
 
 
@@ -53,6 +53,8 @@ def lib():
         L.lrl_scene_rebuild_bvh.argtypes = [C.c_void_p]
         L.lrl_quantize_rgba8.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64]
         L.lrl_water_read.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
+        L.lrl_get_tuning.argtypes = [C.c_void_p, C.POINTER(abi.Tuning)]
+        L.lrl_set_tuning.argtypes = [C.c_void_p, C.POINTER(abi.Tuning)]
         _lib = L
     return _lib
 
@@ -91,6 +93,40 @@ class Tracer:
 
     def scene_upload(self, view):
         self._ck(self._L.lrl_scene_upload(self._ctx, C.byref(view)))
+
+    # ---- LrlTuning ----
+    def get_tuning(self):
+        t = abi.Tuning()
+        self._ck(self._L.lrl_get_tuning(self._ctx, C.byref(t)))
+        return t
+
+    def set_tuning(self, tuning=None, **fields):
+        """set_tuning(t) replaces the knobs; set_tuning(field=value, ...) changes some of the current ones (handoverList: a sequence).
+        Either way the adaptive hand-over thresholds start again."""
+        t = tuning if tuning is not None else self.get_tuning()
+        for k, v in fields.items():
+            if k == "handoverList":
+                v = list(v)
+                t.handoverListLen = len(v)
+                for i, x in enumerate(v):
+                    t.handoverList[i] = int(x)
+            elif not hasattr(t, k):
+                raise AttributeError(k)
+            else:
+                setattr(t, k, v)
+        self._ck(self._L.lrl_set_tuning(self._ctx, C.byref(t)))
+
+    def default_tuning(self):
+        """The knobs lrl_create starts with (a fresh context's)."""
+        t = Tracer.__new__(Tracer)
+        t._L, t._ctx = self._L, C.c_void_p()
+        rc = self._L.lrl_create(0, C.byref(t._ctx))
+        if rc != 0:
+            raise TraceError(rc, "lrl_create failed")
+        try:
+            return t.get_tuning()
+        finally:
+            t.close()
 
     def update_triangles(self, first, tris):
         tris = np.ascontiguousarray(tris, dtype=abi.TRIANGLE)

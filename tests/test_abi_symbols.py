@@ -22,7 +22,7 @@ def test_library_exports_every_declared_symbol():
     L = ctypes.CDLL(tracer.LIB_PATH)
     for s in declared_symbols():
         assert hasattr(L, s), s
-    assert L.lrl_version() == 1
+    assert L.lrl_version() == 2
 
 
 def test_null_arguments_are_rejected_without_a_gpu():

@@ -416,31 +416,23 @@ def test_deep_chain_tree(tracer, n):
     if n <= 60:
         assert tracer.counters().nodeVisits == oc.nodeVisits
     assert tracer.counters().rays == oc.rays
-    saved = {k: os.environ.get(k) for k in ("LRL_ADAPT", "LRL_HANDOVER_LIST")}
+    base = tracer.get_tuning()
     try:
         for early in (False, True):
             if early:
-                os.environ.update(LRL_ADAPT="0", LRL_HANDOVER_LIST="4")
-                tracer.scene_upload(v)
-                tracer.set_camera(tr, W, H)
-                tracer.set_decay_origin((0, 0, 0, 1))
+                tracer.set_tuning(adapt=0, handoverList=[4])
             fast, fhits = tracer.render(max_depth=4, mode=abi.MODE_FAST)
             assert (fhits == ohits).all(axis=-1).mean() >= ID_BAR, early
             assert image_stats(fast, oimg)["rmse"] <= RMSE_FAST, early
     finally:
-        for k, val in saved.items():
-            if val is None:
-                os.environ.pop(k, None)
-            else:
-                os.environ[k] = val
-        tracer.scene_upload(v)                              # thresholds back to their defaults for the tests that follow
+        tracer.set_tuning(base)                             # thresholds back to their defaults for the tests that follow
 
 
 def test_compacted_ray_lists_change_nothing(tracer, default_model, bunny0_model):
     """FAST mode may trace the late segments from compacted lists of the live rays (on by default after diffuse bounces and
-    for scenes beyond the caches; LRL_COMPACT_FROM forces it).  A ray's result does not depend on the lane that carries it:
+    for scenes beyond the caches; LrlTuning.compactFrom forces it).  A ray's result does not depend on the lane that carries it:
     the frames with and without compaction are the same bit for bit, mirror and diffuse."""
-    saved = os.environ.get("LRL_COMPACT_FROM")
+    base = tracer.get_tuning()
     try:
         for m, (W, H) in ((default_model, (200, 160)), (bunny0_model, (320, 180))):
             tr = m.camera(H)
@@ -449,17 +441,14 @@ def test_compacted_ray_lists_change_nothing(tracer, default_model, bunny0_model)
             tracer.set_decay_origin((0, 0, 0, 1))
             for diffuse in (False, True):
                 frames = {}
-                for start in ("0", "1", "3"):
-                    os.environ["LRL_COMPACT_FROM"] = start
+                for start in (0, 1, 3):
+                    tracer.set_tuning(compactFrom=start)
                     frames[start] = tracer.render(max_depth=6, mode=abi.MODE_FAST, diffuse=diffuse)
-                for start in ("1", "3"):
-                    assert np.array_equal(frames[start][0], frames["0"][0]), (diffuse, start)
-                    assert np.array_equal(frames[start][1], frames["0"][1]), (diffuse, start)
+                for start in (1, 3):
+                    assert np.array_equal(frames[start][0], frames[0][0]), (diffuse, start)
+                    assert np.array_equal(frames[start][1], frames[0][1]), (diffuse, start)
     finally:
-        if saved is None:
-            os.environ.pop("LRL_COMPACT_FROM", None)
-        else:
-            os.environ["LRL_COMPACT_FROM"] = saved
+        tracer.set_tuning(base)
 
 
 def test_hand_over_kernels_agree(default_model, bunny0_model):
@@ -467,34 +456,29 @@ def test_hand_over_kernels_agree(default_model, bunny0_model):
     closest hit must come out all the same.  With a threshold of 4 trips nearly every ray goes through them: both must
     agree with each other and with the default schedule (ties between coincident primitives aside, as in the FAST bars)."""
     from raytracing_amd import tracer as T
-    knobs = ("LRL_ADAPT", "LRL_HANDOVER_LIST", "LRL_SWARM_GROUP")
-    saved = {k: os.environ.get(k) for k in knobs}
     t = T.Tracer(0)
+    base = t.get_tuning()
     try:
         for m, (W, H) in ((default_model, (256, 256)), (bunny0_model, (640, 360))):
             tr = m.camera(H)
             res = {}
-            for group in (None, "64", "16"):
-                for k in knobs:
-                    os.environ.pop(k, None)
+            for group in (None, 64, 16):
+                t.set_tuning(base)
                 if group:
-                    os.environ.update(LRL_ADAPT="0", LRL_HANDOVER_LIST="4", LRL_SWARM_GROUP=group)
-                t.scene_upload(m.scene_view())              # the thresholds start again with a scene
+                    t.set_tuning(adapt=0, handoverList=[4], groupLanes=group)
+                t.scene_upload(m.scene_view())
                 t.set_camera(tr, W, H)
                 t.set_decay_origin((0, 0, 0, 1))
                 res[group] = t.render(max_depth=4, mode=abi.MODE_FAST)
-            for group in ("64", "16"):
-                assert (res[group][1] == res[None][1]).all(axis=-1).mean() >= 0.9995, group
-                assert image_stats(res[group][0], res[None][0])["rmse"] <= RMSE_FAST, group
-            assert (res["64"][1] == res["16"][1]).all(axis=-1).mean() >= ID_BAR
-            assert image_stats(res["64"][0], res["16"][0])["rmse"] <= RMSE_FAST
+            for group in (64, 16):
+                same = (res[group][1] == res[None][1]).all(axis=-1).mean()
+                st = image_stats(res[group][0], res[None][0])
+                assert same >= 0.9995, (group, same)
+                assert st["rmse"] <= RMSE_FAST, (group, st)
+            assert (res[64][1] == res[16][1]).all(axis=-1).mean() >= ID_BAR
+            assert image_stats(res[64][0], res[16][0])["rmse"] <= RMSE_FAST
     finally:
         t.close()
-        for k, v in saved.items():
-            if v is None:
-                os.environ.pop(k, None)
-            else:
-                os.environ[k] = v
 
 
 @pytest.mark.parametrize("name", ["bvh_viewB_256", "bvh_viewB_128_spp4", "bvh_inside_glass_128"])

@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Generates tests/golden/: data assets taken from the reference's resources and golden vectors
+"""Generates assets/ (data assets taken from the reference's resources) and tests/golden/ (golden vectors
 rendered by the REFERENCE'S OWN GLSL on Mesa llvmpipe (oracle/_ref/gl_harness).
 
 Runs only where /root/reference is mounted (this container); the outputs are committed so the GPU box,
