@@ -3,6 +3,8 @@ import sys
 
 import numpy as np
 import pytest
+import torch  # noqa: F401  -- first: torch ships its own ROCm runtime libraries; if liblrltrace.so pulls in /opt/rocm's copies before torch is
+#                              imported (a run of one test file that loads the tracer first), torch later finds "No HIP GPUs"
 
 REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 if REPO not in sys.path:

@@ -731,3 +731,61 @@ def test_quantize_rgba8_is_opengl_float_to_unorm(tracer):
     with np.errstate(invalid="ignore"):
         want = np.rint(np.clip(np.nan_to_num(v, nan=0.0, posinf=1.0, neginf=0.0), 0, 1).astype(np.float32) * np.float32(255)).astype(np.uint8)
     assert np.array_equal(dst.cpu().numpy(), want)
+
+
+# ---- samples traced in batches (spp > 1) ----
+@pytest.mark.parametrize("name", ["bvh_viewB_128_spp4", "bvh_inside_glass_128"])
+def test_sample_batches_change_nothing(tracer, default_model, name):
+    """A frame of several samples is traced batch by batch (LrlTuning.batchSlots path slots per launch); the sum over the
+    samples is taken in sample order whatever the batching, so PARITY images and primary ids are bit-identical for batches of
+    1 (the per-sample pipeline), 2 + 2 + 1 and 5 samples, without and with glass (refraction stacks, polled iterations), and
+    with a sample range; FAST differs from itself only through the order-dependent hand-over thresholds (ties)."""
+    g = load_golden(name)
+    W, H = g["width"], g["height"]
+    tracer.scene_upload(default_model.scene_view())
+    tracer.set_camera(g["trans"], W, H)
+    tracer.set_decay_origin(g["decay"].reshape(9, 4)[8] if name == "bvh_inside_glass_128" else (0, 0, 0, 1))
+    jit = host.jitter_table(5)
+    slots = ((W + 7) // 8) * ((H + 7) // 8) * 64
+    slots = (slots + 255) // 256 * 256
+    base = tracer.get_tuning()
+    try:
+        out = {}
+        for mode in (abi.MODE_PARITY, abi.MODE_FAST):
+            for b in (1, 2, 5):
+                tracer.set_tuning(batchSlots=b * slots)
+                out[mode, b] = tracer.render(max_depth=g["depth"], mode=mode, jitter=jit, diffuse=(name == "bvh_viewB_128_spp4"))
+                if b == 2:
+                    part = tracer.render(max_depth=g["depth"], mode=mode, jitter=jit, samples=(1, 4), diffuse=(name == "bvh_viewB_128_spp4"))
+                    tracer.set_tuning(batchSlots=slots)
+                    part1 = tracer.render(max_depth=g["depth"], mode=mode, jitter=jit, samples=(1, 4), diffuse=(name == "bvh_viewB_128_spp4"))
+                    if mode == abi.MODE_PARITY:
+                        assert np.array_equal(part[0].view(np.uint32), part1[0].view(np.uint32)) and np.array_equal(part[1], part1[1])
+        for b in (2, 5):
+            assert np.array_equal(out[abi.MODE_PARITY, b][0].view(np.uint32), out[abi.MODE_PARITY, 1][0].view(np.uint32)), b
+            assert np.array_equal(out[abi.MODE_PARITY, b][1], out[abi.MODE_PARITY, 1][1]), b
+            st = image_stats(out[abi.MODE_FAST, b][0], out[abi.MODE_FAST, 1][0])
+            assert st["rmse"] <= 1e-3 and (out[abi.MODE_FAST, b][1] == out[abi.MODE_FAST, 1][1]).all(axis=-1).mean() >= ID_BAR, (b, st)
+        st = image_stats(out[abi.MODE_FAST, 5][0], out[abi.MODE_PARITY, 5][0])
+        if name == "bvh_viewB_128_spp4":      # diffuse bounces: a direction that moves by an ulp in FAST may land its path on a light's hot spot
+            assert st["frac_gt_1e-3"] <= 2e-3, st
+        else:
+            assert st["rmse"] <= RMSE_FAST, st
+    finally:
+        tracer.set_tuning(base)
+
+
+def test_hit_ids_of_a_sample_range(tracer, default_model):
+    """hit_out holds the primary hits of the FIRST sample a render traces: a render of samples [1, 2) alone (what rank 1 of a
+    sample-sharded frame does) returns the ids a one-sample render with that sample's jitter returns."""
+    g = load_golden("bvh_viewB_128_spp4")
+    tracer.scene_upload(default_model.scene_view())
+    tracer.set_camera(g["trans"], g["width"], g["height"])
+    tracer.set_decay_origin((0, 0, 0, 1))
+    jit = np.asarray(g["jitter"], dtype=np.float32).reshape(-1, 2)
+    for mega in (False, True):
+        _, h_range = tracer.render(max_depth=6, jitter=jit, samples=(1, 2), megakernel=mega)
+        _, h_single = tracer.render(max_depth=6, jitter=jit[1:2], megakernel=mega)
+        _, h_zero = tracer.render(max_depth=6, jitter=jit[0:1], megakernel=mega)
+        assert np.array_equal(h_range, h_single)
+        assert not np.array_equal(h_range, h_zero)           # the jitter moves some edge pixels: the two samples differ
