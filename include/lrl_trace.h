@@ -157,6 +157,15 @@ int lrl_set_tuning(LrlContext* ctx, const LrlTuning* tuning);
 int lrl_scene_upload(LrlContext* ctx, const LrlSceneView* scene);
 /* Pool: water triangles rewritten every frame; re-runs TrianglePre on [first, first+count). */
 int lrl_scene_update_triangles(LrlContext* ctx, uint32_t first, uint32_t count, const LrlTriangle* tris);
+/* The same update for callers that cannot allocate (a frame loop under HIP graph capture, a tight serving loop, a harness that
+ * forbids hipMalloc).  No counterpart in the reference.  Same arguments, same results; it stages the records in a static
+ * device array of the library (LRL_NOALLOC_MAX_TRIANGLES x 164 B = 10.25 MiB per GPU, held until the process ends) instead of
+ * buffers sized to the call, and calls no hipMalloc / hipFree or any other allocating routine.  Limits, refused with
+ * LRL_ERR_LIMIT: count > LRL_NOALLOC_MAX_TRIANGLES; a triangle whose material is not yet in the scene's table (growing the table
+ * allocates).  Every context on one GPU shares that GPU's array: calls that overlap on one GPU (two contexts, two threads)
+ * race; calls on one context follow each other (the call returns when its kernels are done). */
+#define LRL_NOALLOC_MAX_TRIANGLES 65536u
+int lrl_scene_update_triangles_noalloc(LrlContext* ctx, uint32_t first, uint32_t count, const LrlTriangle* tris);
 /* read back device results of the pre-compute kernels (tests / debugging) */
 int lrl_scene_read_triangles_gpu(LrlContext* ctx, uint32_t first, uint32_t count, LrlTriangleGPU* out);
 int lrl_scene_read_circles(LrlContext* ctx, uint32_t first, uint32_t count, LrlCircle* out);

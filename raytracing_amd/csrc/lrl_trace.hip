@@ -8,6 +8,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <mutex>
 #include <string>
 #include <unordered_map>
 #include <vector>
@@ -15,6 +16,14 @@
 #include "lrl_device.h"
 
 #define LRL_WF_MAX_ITERATIONS 4096u   /* ray segments of one path the wavefront pipeline follows at most */
+
+// ---- lrl_scene_update_triangles_noalloc: its staging area ----
+// lrl_scene_update_triangles stages the caller's origin records and their material indices in device buffers it allocates
+// (triStage, matStage) for trianglePreKernel to read.  The no-allocation variant stages them here instead: one array per GPU,
+// part of the code object, held from the library's load until the process ends.  Layout: LRL_NOALLOC_MAX_TRIANGLES origin
+// records (160 B each), then as many material indices (4 B each).  Host code never uses the array's name as an address: lrl_create
+// asks hipGetSymbolAddress for this device's copy (noallocScratchFor) and everything below works on that pointer.
+static __device__ __align__(256) unsigned char scratch[size_t(LRL_NOALLOC_MAX_TRIANGLES) * (sizeof(LrlTriangle) + 4u)];
 
 namespace {
 
@@ -77,6 +86,8 @@ struct LrlContext {
     hipStream_t lastRenderStream = nullptr;
     bool renderedOnce = false;
     LrlTuning tuning{};
+    void* noallocScratch = nullptr;     // this device's copy of the static staging array (lrl_scene_update_triangles_noalloc)
+    std::vector<uint32_t> noallocMat;   // LRL_NOALLOC_MAX_TRIANGLES material indices, allocated in lrl_create
     std::vector<float> workPerRay;      // per iteration: frontier entries per handed-over ray, last feedback
     uint32_t feedbackTick = 0;          // samples rendered since the thresholds were reset
     uint32_t contIters = 0;             // words of contHost in flight / ready
@@ -449,6 +460,27 @@ int runDeviceBuild(LrlContext* c, uint32_t prims, uint32_t& recCount, uint32_t& 
     return LRL_OK;
 }
 
+// this device's copy of `scratch` (each GPU holds its own, at its own address); resolved once per device, with that device current
+constexpr int kMaxDevices = 64;
+std::mutex g_scratchMutex;
+void* g_scratchPtr[kMaxDevices] = {};
+hipError_t noallocScratchFor(int device, void** out) {
+    *out = nullptr;
+    if (device < 0 || device >= kMaxDevices) return hipErrorInvalidDevice;
+    std::lock_guard<std::mutex> lock(g_scratchMutex);
+    if (!g_scratchPtr[device]) {
+        hipError_t e = hipSetDevice(device);
+        if (e != hipSuccess) return e;
+        void* ptr = nullptr;
+        e = hipGetSymbolAddress(&ptr, HIP_SYMBOL(scratch));
+        if (e != hipSuccess) return e;
+        if (!ptr) return hipErrorInvalidSymbol;
+        g_scratchPtr[device] = ptr;
+    }
+    *out = g_scratchPtr[device];
+    return hipSuccess;
+}
+
 LrlTuning defaultTuning() {
     LrlTuning t{};
     t.handoverEarly = 48; t.handoverLate = 16; t.handoverListLen = 0;
@@ -505,6 +537,8 @@ int lrl_create(int device, LrlContext** out) {
               hipEventCreateWithFlags(&c->evCont, hipEventDisableTiming) == hipSuccess &&
               hipEventCreateWithFlags(&c->evLastRender, hipEventDisableTiming) == hipSuccess;
     for (hipEvent_t& e : c->evIter) ok = ok && hipEventCreateWithFlags(&e, hipEventDisableTiming) == hipSuccess;
+    ok = ok && noallocScratchFor(device, &c->noallocScratch) == hipSuccess;
+    if (ok) c->noallocMat.assign(LRL_NOALLOC_MAX_TRIANGLES, 0u);      // host side of the material indices, so that the entry point allocates nothing
     if (!ok) {
         (void)lrl_destroy(c);
         return LRL_ERR_DEVICE;
@@ -729,6 +763,36 @@ int lrl_scene_update_triangles(LrlContext* c, uint32_t first, uint32_t count, co
     if (uint64_t(first) + count > c->num.triangleNum) return fail(c, LRL_ERR_INVALID_ARG, "triangle range out of bounds");
     HIP_TRY(c, hipSetDevice(c->device));
     return runTrianglePre(c, first, count, tris);
+}
+
+int lrl_scene_update_triangles_noalloc(LrlContext* c, uint32_t first, uint32_t count, const LrlTriangle* tris) {
+    if (!c || (count && !tris)) return LRL_ERR_INVALID_ARG;
+    if (!c->haveScene) return fail(c, LRL_ERR_NO_SCENE, "no scene uploaded");
+    if (uint64_t(first) + count > c->num.triangleNum) return fail(c, LRL_ERR_INVALID_ARG, "triangle range out of bounds");
+    if (count > LRL_NOALLOC_MAX_TRIANGLES) return fail(c, LRL_ERR_LIMIT, "lrl_scene_update_triangles_noalloc: count exceeds LRL_NOALLOC_MAX_TRIANGLES (the static staging area); update in pieces or use lrl_scene_update_triangles");
+    if (!count) return LRL_OK;
+    if (!c->noallocScratch) return fail(c, LRL_ERR_DEVICE, "the static staging area was not resolved for this device");
+    HIP_TRY(c, hipSetDevice(c->device));
+    // materials: looked up only; a new one would grow the table (host and device allocations)
+    for (uint32_t i = 0; i < count; ++i) {
+        ColorKey k;
+        std::memcpy(k.w, &tris[i].color, sizeof(k.w));
+        auto it = c->materialIndex.find(k);
+        if (it == c->materialIndex.end())
+            return fail(c, LRL_ERR_LIMIT, "lrl_scene_update_triangles_noalloc: a triangle carries a material that is not in the scene's table (adding one allocates); use lrl_scene_update_triangles");
+        c->noallocMat[i] = it->second;
+    }
+    unsigned char* const area = static_cast<unsigned char*>(c->noallocScratch);
+    LrlTriangle* const stageTris = reinterpret_cast<LrlTriangle*>(area);
+    uint32_t* const stageMat = reinterpret_cast<uint32_t*>(area + size_t(LRL_NOALLOC_MAX_TRIANGLES) * sizeof(LrlTriangle));
+    // the area keeps the last call's records beyond `count`: nothing reads them, the kernels stop at `count`
+    HIP_TRY(c, hipMemcpyAsync(stageTris, tris, size_t(count) * sizeof(LrlTriangle), hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(c, hipMemcpyAsync(stageMat, c->noallocMat.data(), size_t(count) * 4, hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(c, lrl_launch_triangle_pre(stageTris, stageMat, first, count, static_cast<float4*>(c->triHot.p), static_cast<LrlTriCold*>(c->triCold.p), c->stream));
+    if (c->deviceBuilt)      // keep the boxes current for lrl_scene_rebuild_bvh
+        HIP_TRY(c, lrl_launch_triangle_boxes(stageTris, first, count, static_cast<float4*>(c->primMin.p), static_cast<float4*>(c->primMax.p), c->stream));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));   // the caller's array is borrowed only for this call; the staging area is free again
+    return LRL_OK;
 }
 
 int lrl_scene_read_triangles_gpu(LrlContext* c, uint32_t first, uint32_t count, LrlTriangleGPU* out) {

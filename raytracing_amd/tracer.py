@@ -20,6 +20,7 @@ EXPORTS = [
     "lrl_scene_read_triangles_gpu", "lrl_scene_read_circles", "lrl_set_camera", "lrl_set_decay_origin", "lrl_compute_decay_origin",
     "lrl_render", "lrl_render_async", "lrl_sync", "lrl_get_counters", "lrl_last_kernel_ms", "lrl_scene_device_bytes",
     "lrl_timing_begin", "lrl_timing_end", "lrl_water_init", "lrl_water_step", "lrl_water_read", "lrl_scene_rebuild_bvh", "lrl_quantize_rgba8", "lrl_get_tuning", "lrl_set_tuning",
+    "lrl_scene_update_triangles_noalloc",
 ]
 
 
@@ -35,6 +36,7 @@ def lib():
         L.lrl_destroy.argtypes = [C.c_void_p]
         L.lrl_scene_upload.argtypes = [C.c_void_p, C.POINTER(abi.SceneView)]
         L.lrl_scene_update_triangles.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32, C.c_void_p]
+        L.lrl_scene_update_triangles_noalloc.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32, C.c_void_p]
         L.lrl_scene_read_triangles_gpu.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32, C.c_void_p]
         L.lrl_scene_read_circles.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32, C.c_void_p]
         L.lrl_set_camera.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32]
@@ -131,6 +133,11 @@ class Tracer:
     def update_triangles(self, first, tris):
         tris = np.ascontiguousarray(tris, dtype=abi.TRIANGLE)
         self._ck(self._L.lrl_scene_update_triangles(self._ctx, first, tris.shape[0], tris.ctypes.data_as(C.c_void_p)))
+
+    def update_triangles_noalloc(self, first, tris):
+        """lrl_scene_update_triangles_noalloc: the same update through the library's static staging array (allocates nothing)."""
+        tris = np.ascontiguousarray(tris, dtype=abi.TRIANGLE)
+        self._ck(self._L.lrl_scene_update_triangles_noalloc(self._ctx, first, tris.shape[0], tris.ctypes.data_as(C.c_void_p)))
 
     def read_triangles_gpu(self, first, count):
         out = np.zeros(count, dtype=abi.TRIANGLE_GPU)
