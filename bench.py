@@ -1,32 +1,40 @@
 #!/usr/bin/env python3
 """bench.py — Mrays/s of the hot path on the BASELINE.json headline configuration.
 
-Workload (BASELINE.json configs[1]): Stanford bunny x 2 midpoint subdivisions
-(1 240 960 triangles) + ground disc + 1 point light, 1920x1080, 1 spp, 4 bounces.  A "step" is one
-frame: the wavefront pipeline (generate, then trace + shade per ray segment) over every pixel, scene
-and camera already resident in HBM, image written to HBM.  rays = primary + reflection + refraction
-+ shadow segments (device counters of an un-timed counting render, which walks the tree in the
-reference's order; checked against the CPU oracle in tests/).
+Default workload (BASELINE.json configs[1]): Stanford bunny x 2 midpoint subdivisions (1 240 960 triangles) + ground
+disc + 1 point light, 1920x1080, 1 spp, 4 bounces.  A "step" is one frame: the wavefront pipeline (generate, then trace + shade per
+ray segment) over every pixel, scene and camera already resident in HBM, image written to HBM.  rays = primary + reflection +
+refraction + shadow segments (device counters of an un-timed counting render that walks the tree in the reference's order; equal to
+the CPU oracle's counts, tests/).
 
-Roofline: the dominant kernels are the trace kernels (one launch per ray segment: 5 per frame here).
-achieved = algorithmic bytes of one frame / device time of that frame's trace launches, timed with
-HIP events around every trace launch in a separate short pass (the event records add gaps, so that
-pass is not the one `value` comes from).  frame_ms is the device time of the whole pipeline.
+  python bench.py [--gpus N] [--steps K] [--warmup W] [--workload c1|c2|c3|c4|c5] [--scaling weak|strong] [--mode fast|parity]
+                  [--builder reference|median|device] [--tuning key=value,...]
 
-N > 1 (torchrun, one rank per GPU): the scene is replicated; every rank renders the whole frame for
-its own sample(s) of an N x spp jitter table (sample-index sharding, so per-GPU work is fixed: weak
-scaling) and the partial means are summed with one RCCL all-reduce per step, inside the timed
-region; the all-reduce of a frame overlaps the rendering of the next one (two image buffers).
+Roofline (two records in the one JSON line):
+  roofline     the timed workload.  C1-C4 touch a working set that sits in the 256 MiB Infinity Cache (C2: 160 MB), so no HBM number
+               bounds them; what does is the vector L1's gather rate (one 64-B record per lane and trip).  `achieved` = bytes the
+               timed trace kernels fetch (64 B x their record fetches, counted by a counting instantiation of those same kernels) /
+               their device time (HIP events around every trace launch, on the stream they run on); `peak` = the L1 gather rate of
+               that access shape measured on this chip (tools/probes/l1_gather.hip: 171 CU-cycles per wave of 64 own-record
+               loads = 14.7 TB/s; the guide has no L1 figure); `traffic` = bytes beyond L2 from the PMC passes (profiles/);
+               `hbm_frac` = traffic / kernel time / 8 TB/s; `work` = SURVEY 8d's algorithmic bytes (reference-order visit counts).
+  roofline_c5  SURVEY 8d's C5, the configuration the memory roofline is judged on (100.5 M triangles, device-built tree, diffuse
+               bounces, 16 spp; 22 GB of scene, far beyond the caches): `achieved` = algorithmic bytes / trace-kernel time against
+               the 8 TB/s HBM peak, with PMC traffic and hbm_frac.  N = 1 default runs only (--no-c5 skips it).
+
+N > 1 (one rank per GPU; `python bench.py --gpus N` starts the ranks itself through torch.distributed.run when it is not already
+under one): the scene is replicated.
+  --scaling weak   (default for c1/c2/c3/c5) every rank renders the whole frame for its own sample indices of an N x spp jitter table
+                   (per-GPU work fixed); the partial means are summed with one RCCL all-reduce per step inside the timed region, which
+                   overlaps the rendering of the next frame (two image buffers, stream-level waits only).
+  --scaling strong (default for c4: ONE 3840x2160 x 256 spp frame of the C2 scene) every rank renders its interleaved 16-row stripes
+                   (LrlRenderParams.rowInterleave, one call), one RCCL all-gather per frame inside the timed region + the un-interleave.
 value = rays of all ranks / max-over-ranks time.
-
-  python bench.py [--gpus N] [--steps K] [--warmup W] [--mode fast|parity] [--builder reference|median] [--workload c2|c3]
-
---workload c3 measures SURVEY 8d's C3 (Pool demo scene, Pool shader variant, 64 spp, depth 8) the same way; it is not the
-headline line.
 """
 import argparse
 import json
 import os
+import subprocess
 import sys
 import time
 
@@ -34,254 +42,455 @@ REPO = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, REPO)
 
 HBM_PEAK_GBPS = 8000.0          # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8 TB/s (spec)
+# vector-L1 gather rate for this kernel's access shape (every lane its own 64-B record, four dwordx4 loads): 171 CU-cycles per
+# wave-round from L1 (tools/probes/l1_gather.hip on MI355X, gpurun_out/l1_gather.txt) = 4096 B / 171 cycles x 256 CUs x 2.4 GHz
+L1_GATHER_PEAK_GBPS = 4096.0 / 171.2 * 256 * 2.4
+INFINITY_CACHE_BYTES = 256 << 20
+
+WORKLOADS = {
+    #        width height depth spp  variant grid diffuse builder      scaling
+    "c1": (1024, 1024, 10, 1, "bvh", 1, False, "reference", "weak"),
+    "c2": (1920, 1080, 4, 1, "bvh", 1, False, "reference", "weak"),
+    "c3": (1920, 1080, 8, 64, "pool", 1, False, "reference", "weak"),
+    "c4": (3840, 2160, 4, 256, "bvh", 1, False, "reference", "strong"),
+    "c5": (1920, 1080, 4, 16, "bvh", 9, True, "device", "weak"),
+}
+
+
+def parse_args():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=0, help="0 = the workload's own (50 for c1/c2, 5 for c3/c5, 3 for c4)")
+    ap.add_argument("--warmup", type=int, default=-1, help="-1 = the workload's own")
+    ap.add_argument("--mode", default="fast", choices=["fast", "parity"])
+    ap.add_argument("--builder", default="", choices=["", "reference", "median", "device"],
+                    help="who builds the BVH: the restated reference builder (host), a median-split host builder, or the library on the device")
+    ap.add_argument("--subdivisions", type=int, default=2)
+    ap.add_argument("--width", type=int, default=0)
+    ap.add_argument("--height", type=int, default=0)
+    ap.add_argument("--depth", type=int, default=0, help="RayTraceDepth (0 = the workload's own)")
+    ap.add_argument("--workload", default="c2", choices=sorted(WORKLOADS),
+                    help="c2 (default, the headline metric's configuration) | c1: the reference's default BVH scene as shipped, 1024 x 1024 | "
+                         "c3: Pool demo scene, 64 spp | c4: the c2 scene at 3840 x 2160 x 256 spp | c5: 100.5 M triangles, diffuse bounces, 16 spp")
+    ap.add_argument("--grid", type=int, default=0, help="mesh scenes: grid x grid replicated copies of the mesh (9 -> 100.5 M triangles)")
+    ap.add_argument("--spp", type=int, default=0, help="samples per pixel (0 = the workload's own)")
+    ap.add_argument("--diffuse", action="store_true", help="LRL_FLAG_DIFFUSE_BOUNCE: cosine-weighted continuation rays (c5 has it on)")
+    ap.add_argument("--scaling", default="", choices=["", "weak", "strong"])
+    ap.add_argument("--tuning", default="", help="LrlTuning fields, e.g. batchSlots=4194304,adapt=0,handoverList=48:48:32:16")
+    ap.add_argument("--no-overlap", action="store_true", help="N > 1, weak: the all-reduce of a frame does not overlap the next frame")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-c5", action="store_true", help="skip the roofline_c5 record of the default run")
+    ap.add_argument("--cpu-rows", type=int, default=0, help="rows of the frame the CPU baseline renders (0 = all)")
+    ap.add_argument("--rehearse", action="store_true",
+                    help="N > 1 on a one-GPU box (never the measured configuration): every rank on GPU 0, gloo instead of RCCL (which refuses two ranks on one device)")
+    return ap.parse_args()
+
+
+def spawn_ranks(a):
+    """`python bench.py --gpus N` outside torchrun: start N ranks with torch.distributed.run as CHILD processes.  Nothing in this
+    process has touched the GPU (no exec of a process that has)."""
+    import socket
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={a.gpus}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    return subprocess.run(cmd, env=env).returncode
+
+
+def apply_tuning(tr, spec):
+    if not spec:
+        return
+    kw = {}
+    for item in spec.split(","):
+        k, v = item.split("=")
+        if k == "handoverList":
+            kw[k] = [int(x) for x in v.split(":")]
+        elif k == "workLow":
+            kw[k] = float(v)
+        else:
+            kw[k] = int(v)
+    tr.set_tuning(**kw)
+
+
+def load_traffic(name, match):
+    """PMC passes are separate runs (tools/run_pmc.sh); their per-frame byte counts live in profiles/."""
+    path = os.path.join(REPO, "profiles", name)
+    if not os.path.exists(path):
+        return None
+    tj = json.load(open(path))
+    for k, v in match.items():
+        if tj.get(k) != v:
+            return None
+    return tj.get("hbm_bytes_per_frame")
+
+
+class Workload:
+    """One scene + camera + render parameters on one tracer context."""
+
+    def __init__(self, a, name, local_rank, world, rank, scaling):
+        from raytracing_amd import abi, host, scenes, tracer
+        W, H, depth, spp, variant, grid, diffuse, builder, _ = WORKLOADS[name]
+        self.name = name
+        self.W, self.H = a.width or W, a.height or H
+        self.depth = a.depth or depth
+        self.spp = a.spp or spp
+        self.grid = a.grid or grid
+        self.diffuse = a.diffuse or diffuse
+        self.builder = a.builder or builder
+        self.subdivisions = a.subdivisions
+        self.variant = abi.VARIANT_POOL if variant == "pool" else abi.VARIANT_BVH
+        self.mode = abi.MODE_FAST if a.mode == "fast" else abi.MODE_PARITY
+        self.mode_name = a.mode
+        self.world, self.rank, self.scaling = world, rank, scaling
+        t0 = time.time()
+        if name == "c3":
+            m = scenes.pool(builder="reference" if self.builder == "device" else self.builder)
+        elif name == "c1":
+            m = scenes.bvh_default(builder="reference" if self.builder == "device" else self.builder)
+        else:
+            m = scenes.mesh_scene(subdivisions=a.subdivisions, builder="none" if self.builder == "device" else self.builder, grid=self.grid)
+        self.build_s = time.time() - t0
+        self.model = m
+        self.trans = m.camera(self.H)
+        self.view = m.scene_view()
+        if self.builder == "device":
+            self.view.bvh = None
+            self.view.bvhNodeNum = 0
+        self.tr = tracer.Tracer(local_rank)
+        apply_tuning(self.tr, a.tuning)
+        t0 = time.time()
+        self.tr.scene_upload(self.view)
+        self.upload_s = time.time() - t0
+        self.tr.set_camera(self.trans, self.W, self.H)
+        self.tr.set_decay_origin((0, 0, 0, 1))
+        self.info = self.tr.scene_info()
+        # weak: every rank renders spp samples of a (spp * world)-entry jitter table, the whole frame
+        # strong: every rank renders all spp samples of its interleaved stripes
+        if scaling == "weak":
+            total = self.spp * world
+            self.jitter = host.jitter_table(total) if total > 1 else None
+            self.samples = (rank * self.spp, (rank + 1) * self.spp) if world > 1 else None
+            self.rows = None
+        else:
+            self.jitter = host.jitter_table(self.spp) if self.spp > 1 else None
+            self.samples = None
+            self.rows = ("interleave", world, rank) if world > 1 else None
+        self.out_rows = self.tr.shard_rows(world, rank) if self.rows else self.H
+
+    def kw(self):
+        return dict(max_depth=self.depth, variant=self.variant, mode=self.mode, jitter=self.jitter, samples=self.samples, rows=self.rows,
+                    diffuse=self.diffuse)
+
+    def count(self):
+        """Un-timed counting renders of this rank's share: rays + algorithmic bytes (reference visit order), and the record fetches of
+        the FAST kernels themselves."""
+        tr = self.tr
+        tr.render(counters=True, want_hits=False, **self.kw())
+        cn = tr.counters()
+        self.cn = cn
+        self.rays, self.alg_bytes = cn.rays, cn.algorithmic_bytes()
+        self.fetch_bytes = None
+        if self.mode_name == "fast":
+            tr.render(count_fetches=True, want_hits=False, **self.kw())
+            self.fetch_bytes = 64 * int(tr.counters().recordFetches)
+
+    def render_into(self, ptr, stream=None, time_kernels=False):
+        self.tr.render_device(ptr, stream=stream, time_kernels=time_kernels, **self.kw())
+
+    def trace_kernel_ms(self, ptr, frames):
+        """Device time of the trace launches of one frame: HIP events around every trace launch (a separate short pass: the event
+        records add gaps, so it is not the pass `value` comes from).  The library keeps 4096 event pairs."""
+        self.tr.timing_begin()
+        for _ in range(frames):
+            self.render_into(ptr, time_kernels=True)
+        self.tr.sync()
+        ms, launches = self.tr.timing_end()
+        return ms / frames, launches // frames
+
+    def describe(self):
+        n = self.view.num.triangleNum
+        if self.name == "c1":
+            s = f"C1: the reference's default BVH scene ({n} triangles + spheres, discs, cylinders, cones), "
+        elif self.name == "c3":
+            s = f"C3: Pool demo scene ({n} triangles, water at rest), Pool shader variant, "
+        else:
+            s = (f"{self.name.upper()}: Stanford bunny x{self.subdivisions} subdivisions"
+                 f"{f', {self.grid}x{self.grid} copies' if self.grid > 1 else ''} ({n} triangles) + ground disc + 1 light, ")
+        s += f"{self.W}x{self.H}, {self.spp} spp" + (" per GPU" if self.scaling == "weak" and self.world > 1 else "") + f", RayTraceDepth {self.depth}"
+        return s + (", diffuse bounces (Philox, cosine-weighted)" if self.diffuse else "")
+
+    def working_set(self):
+        d = self.tr.scene_device_bytes()
+        # a FAST frame touches the four-wide nodes (half of `nodes`), the hot triangle records and the cold ones of the hits
+        return d["nodes"] // 2 + d["tri_hot"] + d["tri_cold"] + d["other"]
+
+    def roofline(self, kernel_ms, launches, frame_ms, traffic):
+        resident = self.working_set() <= INFINITY_CACHE_BYTES
+        r = {"kernel": ("trace kernels of one frame (wfTraceLeanKernel + wfTraceGroupKernel)" if self.mode_name == "fast"
+                        else "trace kernels of one frame (wfTraceKernel)"),
+             "kernel_ms": round(kernel_ms, 4), "launches_per_frame": launches, "frame_ms": round(frame_ms, 4),
+             "working_set_bytes": self.working_set(), "traffic": traffic,
+             "hbm_frac": round(traffic / (kernel_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS, 5) if traffic else None,
+             "work": {"algorithmic_bytes_per_frame": int(self.alg_bytes),
+                      "algorithmic_GBps": round(self.alg_bytes / (kernel_ms * 1e-3) / 1e9, 2),
+                      "counts": {"node_visits": int(self.cn.nodeVisits), "tri_tests": int(self.cn.triTests), "sphere_tests": int(self.cn.sphereTests),
+                                 "other_tests": int(self.cn.otherTests), "rays": int(self.rays)}}}
+        if resident and self.fetch_bytes:
+            ach = self.fetch_bytes / (kernel_ms * 1e-3) / 1e9
+            r.update({"bound": "l1", "level": "vector L1 gather rate; the working set is resident in the Infinity Cache / L2, HBM is nearly idle",
+                      "achieved": round(ach, 2), "peak": round(L1_GATHER_PEAK_GBPS, 1), "unit": "GB/s", "frac": round(ach / L1_GATHER_PEAK_GBPS, 5),
+                      "fetched_bytes_per_frame": int(self.fetch_bytes)})
+        else:
+            ach = self.alg_bytes / (kernel_ms * 1e-3) / 1e9
+            r.update({"bound": "hbm", "level": "HBM: the working set is far beyond the 256 MiB Infinity Cache" if not resident else "Infinity Cache resident",
+                      "achieved": round(ach, 2), "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBPS, 5),
+                      "fetched_bytes_per_frame": int(self.fetch_bytes) if self.fetch_bytes else None})
+        if not (0.0 < r["frac"] <= 1.0):
+            r["frac_note"] = "frac outside (0, 1]: the caches serve part of these bytes; see hbm_frac and work"
+        return r
 
 
 def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=50)
-    ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--mode", default="fast", choices=["fast", "parity"])
-    ap.add_argument("--builder", default="reference", choices=["reference", "median", "device"],
-                    help="who builds the BVH: the restated reference builder (host, default), a median-split host builder, or the library on the device")
-    ap.add_argument("--subdivisions", type=int, default=2)
-    ap.add_argument("--width", type=int, default=0, help="0 = the workload's own: 1920 (c1: 1024)")
-    ap.add_argument("--height", type=int, default=0, help="0 = the workload's own: 1080 (c1: 1024)")
-    ap.add_argument("--depth", type=int, default=0, help="RayTraceDepth (0 = the workload's own: 4 for c2, 8 for c3)")
-    ap.add_argument("--workload", default="c2", choices=["c1", "c2", "c3"],
-                    help="c2 (default, the headline metric's configuration) | c1: the reference's default BVH scene as shipped, 1024 x 1024, "
-                         "RayTraceDepth 10 | c3: Pool demo scene, Pool shader variant, 64 spp (SURVEY 8d)")
-    ap.add_argument("--grid", type=int, default=1, help="c2 only: grid x grid replicated copies of the mesh (towards C5: 9 -> 100.5 M triangles)")
-    ap.add_argument("--spp", type=int, default=0, help="samples per pixel (0 = the workload's own: 1 for c2, 64 for c3)")
-    ap.add_argument("--diffuse", action="store_true", help="LRL_FLAG_DIFFUSE_BOUNCE: cosine-weighted continuation rays (SURVEY 8d C5: incoherent secondary rays)")
-    ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-rows", type=int, default=0, help="rows of the frame the CPU baseline renders (0 = auto)")
-    a = ap.parse_args()
+    a = parse_args()
+    if a.gpus > 1 and "RANK" not in os.environ:
+        sys.exit(spawn_ranks(a))
 
-    import numpy as np
     import torch
     import torch.distributed as dist
 
-    from raytracing_amd import abi, host, scenes, tracer
+    from raytracing_amd import sharding
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if world != a.gpus:
-        raise SystemExit(f"--gpus {a.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {a.gpus}")
+        raise SystemExit(f"--gpus {a.gpus} but WORLD_SIZE={world}")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the HIP path has no CPU fallback")
-    # rehearsal on a one-GPU box only (never the measured configuration): LRL_BENCH_REHEARSE=1 puts every rank on GPU 0 and
-    # combines over gloo, to run the N > 1 code path end to end where RCCL cannot (it refuses two ranks on one device)
-    rehearse = world > 1 and os.environ.get("LRL_BENCH_REHEARSE") == "1"
+    rehearse = world > 1 and a.rehearse
     if rehearse:
         local_rank = 0
         import faulthandler
-        faulthandler.dump_traceback_later(180, exit=True)     # a hang names its line
+        faulthandler.dump_traceback_later(240, exit=True)     # a hang names its line
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        if rehearse:
-            dist.init_process_group(backend="gloo")
+        dist.init_process_group(backend="gloo" if rehearse else "nccl", **({} if rehearse else {"device_id": dev}))
+
+    ok = True
+    try:
+        run(a, torch, dist, sharding, rank, local_rank, world, dev, rehearse)
+    except BaseException:
+        ok = False
+        import traceback
+        traceback.print_exc()
+    if world > 1:
+        if ok:
+            dist.barrier()
+            dist.destroy_process_group()
         else:
-            dist.init_process_group(backend="nccl", device_id=dev)
+            os._exit(1)      # no collective error path: the launcher ends the other ranks
+    elif not ok:
+        sys.exit(1)
 
-    # ---- scene: built on the host by the restated reference library, uploaded once ----
-    t0 = time.time()
-    c1, c3 = a.workload == "c1", a.workload == "c3"
-    a.width = a.width or (1024 if c1 else 1920)
-    a.height = a.height or (1024 if c1 else 1080)
-    a.depth = a.depth or (10 if c1 else 8 if c3 else 4)
-    a.spp = a.spp or (64 if c3 else 1)
-    variant = abi.VARIANT_POOL if c3 else abi.VARIANT_BVH
-    if c3:
-        m = scenes.pool(builder="reference" if a.builder == "device" else a.builder)      # (the Pool model always builds its tree; not handed over)
-    elif c1:
-        m = scenes.bvh_default(builder="reference" if a.builder == "device" else a.builder)
+
+def run(a, torch, dist, sharding, rank, local_rank, world, dev, rehearse):
+    scaling = a.scaling or WORKLOADS[a.workload][8]
+    steps = a.steps or {"c1": 50, "c2": 50, "c3": 5, "c4": 3, "c5": 5}[a.workload]
+    warmup = a.warmup if a.warmup >= 0 else {"c1": 5, "c2": 5, "c3": 2, "c4": 1, "c5": 2}[a.workload]
+    wl = Workload(a, a.workload, local_rank, world, rank, scaling)
+    wl.count()
+    W, H = wl.W, wl.H
+
+    stream = torch.cuda.Stream(device=dev) if world > 1 else None
+    raw = stream.cuda_stream if stream else None
+    if scaling == "strong":
+        index = sharding.interleave_index(H, world)
+        idx_dev, pad = index[0].to(dev), index[1]
+        part = torch.zeros((pad, W, 4), dtype=torch.float32, device=dev)
+        gathered = torch.empty((world * pad, W, 4), dtype=torch.float32, device=dev) if world > 1 else part
+        frame = [None]
+        outs = [part]
     else:
-        m = scenes.mesh_scene(subdivisions=a.subdivisions, builder="none" if a.builder == "device" else a.builder, grid=a.grid)
-    build_s = time.time() - t0
-    info = m.bvh_info() if a.builder != "device" or c3 or c1 else {"nodes": 0, "max_depth": 0}
-    W, H = a.width, a.height
-    trans = m.camera(H)
-    view = m.scene_view()
-    if a.builder == "device":
-        view.bvh = None
-        view.bvhNodeNum = 0
-    tr = tracer.Tracer(local_rank)
-    t0 = time.time()
-    tr.scene_upload(view)
-    upload_s = time.time() - t0
-    tr.set_camera(trans, W, H)
-    tr.set_decay_origin((0, 0, 0, 1))
-    mode = abi.MODE_FAST if a.mode == "fast" else abi.MODE_PARITY
-    # every rank renders a.spp samples of an (a.spp * world)-entry jitter table: per-GPU work is fixed (weak scaling)
-    total_spp = a.spp * world
-    jitter = host.jitter_table(total_spp) if total_spp > 1 else None
-    samples = (rank * a.spp, (rank + 1) * a.spp) if world > 1 else None
-
-    # ---- ray / node / primitive-test counts of this rank's frame (counting variant, un-timed) ----
-    _, _ = tr.render(max_depth=a.depth, variant=variant, mode=mode, counters=True, jitter=jitter, samples=samples, want_hits=False, diffuse=a.diffuse)
-    cn = tr.counters()
-    rays, alg_bytes = cn.rays, cn.algorithmic_bytes()
-
-    out = torch.empty((H, W, 4), dtype=torch.float32, device=dev)
-    # N > 1: two image buffers, so that the all-reduce of frame i (RCCL's own stream) runs while frame i + 1 renders.  The
-    # render stream waits for the collective that last used a buffer before rendering into it again (stream-level waits
-    # only, no host wait inside the loop); every step still does one render and one all-reduce.
-    outs = [out, torch.empty_like(out)] if world > 1 else [out]
+        outs = [torch.empty((H, W, 4), dtype=torch.float32, device=dev) for _ in range(2 if world > 1 else 1)]
     works = [None, None]
-    render_stream = torch.cuda.Stream(device=dev) if world > 1 else None
     counter = [0]
-
-    # LRL_BENCH_OVERLAP=1: the all-reduce of frame i overlaps the render of frame i + 1 (two buffers, one collective in
-    # flight).  Not the default: its two-rank rehearsal over gloo (whose collectives block a worker thread inside HIP waits)
-    # stalled now and then in the timed loop, and a stalled scaling run measures nothing; RCCL has no such thread, so the
-    # overlap is there to be switched on once it has run on a multi-GPU node.
-    overlap = os.environ.get("LRL_BENCH_OVERLAP") == "1"
+    overlap = world > 1 and scaling == "weak" and not a.no_overlap
 
     def step():
         if world == 1:
-            tr.render_device(out.data_ptr(), max_depth=a.depth, variant=variant, mode=mode, jitter=jitter, samples=samples, diffuse=a.diffuse)
+            wl.render_into(outs[0].data_ptr())
+            if scaling == "strong":
+                frame[0] = part.index_select(0, idx_dev)          # the same un-interleave the N-rank frame pays
             return
-        if not overlap:
-            # default: the frame and its all-reduce one after the other on one stream (RCCL: both are only enqueued)
-            counter[0] += 1
-            with torch.cuda.stream(render_stream):
-                tr.render_device(outs[0].data_ptr(), stream=render_stream.cuda_stream, max_depth=a.depth, variant=variant, mode=mode,
-                                 jitter=jitter, samples=samples, diffuse=a.diffuse)
+        with torch.cuda.stream(stream):
+            if scaling == "strong":
+                # one frame: my interleaved stripes, one all-gather, un-interleave
+                wl.render_into(part.data_ptr(), stream=raw)
+                dist.all_gather_into_tensor(gathered, part)
+                frame[0] = gathered.index_select(0, idx_dev)
+            elif not overlap:
+                wl.render_into(outs[0].data_ptr(), stream=raw)
                 dist.all_reduce(outs[0], op=dist.ReduceOp.SUM)
-            if rehearse:
-                print(f"[rehearsal] rank {rank}: step {counter[0]} done", file=sys.stderr, flush=True)
-            return
-        b = counter[0] & 1
+            else:
+                # frame i renders (into the buffer whose all-reduce, of frame i - 2, was waited for in the last step) while the
+                # all-reduce of frame i - 1 runs; then that one is waited for (RCCL: a wait of the render stream, not of the host)
+                # and the all-reduce of frame i is queued behind its render: never more than one collective in flight
+                b = counter[0] & 1
+                wl.render_into(outs[b].data_ptr(), stream=raw)
+                if works[1 - b] is not None:
+                    works[1 - b].wait()
+                    works[1 - b] = None
+                works[b] = dist.all_reduce(outs[b], op=dist.ReduceOp.SUM, async_op=True)
         counter[0] += 1
-        with torch.cuda.stream(render_stream):
-            # frame i renders (into the buffer whose all-reduce, of frame i - 2, was waited for in the last step) while the
-            # all-reduce of frame i - 1 runs; then that one is waited for (RCCL: a wait of the render stream, not of the
-            # host) and the all-reduce of frame i is queued behind its render: never more than one collective in flight
-            tr.render_device(outs[b].data_ptr(), stream=render_stream.cuda_stream, max_depth=a.depth, variant=variant, mode=mode,
-                             jitter=jitter, samples=samples, diffuse=a.diffuse)
-            if works[1 - b] is not None:
-                works[1 - b].wait()
-                works[1 - b] = None
-            works[b] = dist.all_reduce(outs[b], op=dist.ReduceOp.SUM, async_op=True)
         if rehearse:
             print(f"[rehearsal] rank {rank}: step {counter[0]} queued", file=sys.stderr, flush=True)
-            if os.environ.get("LRL_BENCH_REHEARSE_SYNC") == "1":      # tells a render that never ends from a collective that never ends
-                render_stream.synchronize()
-                print(f"[rehearsal] rank {rank}: step {counter[0]} rendered", file=sys.stderr, flush=True)
 
     def drain():
         for i in (0, 1):
             if works[i] is not None:
                 works[i].wait()
                 works[i] = None
-        tr.sync()
+        wl.tr.sync()
         torch.cuda.synchronize()
 
-    for _ in range(a.warmup):
+    for _ in range(warmup):
         step()
     drain()
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
-    tr.timing_begin()
+    wl.tr.timing_begin()
     t0 = time.perf_counter()
-    for _ in range(a.steps):
+    for _ in range(steps):
         step()
     drain()
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
-    frame_ms_total, frames = tr.timing_end()
+    frame_ms_total, frames = wl.tr.timing_end()
 
-    # ---- trace-kernel time of one frame (HIP events around every trace launch), separate short pass ----
-    # (the library keeps at most 4096 timed launches: one frame is enough where a frame has hundreds of them)
-    TRACE_FRAMES = 5 if a.spp <= 64 else 1
-    tr.timing_begin()
-    for _ in range(TRACE_FRAMES):
-        tr.render_device(out.data_ptr(), max_depth=a.depth, variant=variant, mode=mode, jitter=jitter, samples=samples, time_kernels=True, diffuse=a.diffuse)
-    tr.sync()
-    trace_ms_total, trace_launches = tr.timing_end()
+    scratch_out = outs[0].data_ptr()
+    kernel_ms, launches = wl.trace_kernel_ms(scratch_out, 5 if wl.spp <= 16 else 1)
+    rinfo = wl.tr.last_render_info()
 
-    tot = torch.tensor([elapsed, float(rays), float(alg_bytes)], dtype=torch.float64, device=dev)
+    tot = torch.tensor([elapsed, float(wl.rays)], dtype=torch.float64, device=dev)
     if world > 1:
         mx = tot.clone()
         dist.all_reduce(mx, op=dist.ReduceOp.MAX)
         dist.all_reduce(tot, op=dist.ReduceOp.SUM)
-        elapsed = float(mx[0])
-        rays_all = float(tot[1])
+        elapsed, rays_all = float(mx[0]), float(tot[1])
     else:
-        rays_all = float(rays)
+        rays_all = float(wl.rays)
 
-    if rank == 0:
-        ms_per_step = elapsed / a.steps * 1e3
-        value = rays_all * a.steps / elapsed / 1e6
-        frame_ms = frame_ms_total / max(frames, 1)
-        kernel_ms = trace_ms_total / TRACE_FRAMES
-        if trace_launches >= 4096:
-            raise SystemExit("bench.py: more trace launches per timed pass than the library keeps events for; lower --spp")
-        achieved = alg_bytes / (kernel_ms * 1e-3) / 1e9
-        traffic = None
-        tpath = os.path.join(REPO, "profiles", "r01_traffic.json")        # PMC passes are separate runs (tools/run_pmc.sh)
-        if os.path.exists(tpath):
-            tj = json.load(open(tpath))
-            if (tj.get("workload_triangles") == int(view.num.triangleNum) and tj.get("mode") == a.mode and tj.get("builder") == a.builder
-                    and not a.diffuse and (W, H, a.spp, a.depth) == (1920, 1080, 1, 4)):      # what the PMC passes ran
-                traffic = tj.get("hbm_bytes_per_frame")
-        dbytes = tr.scene_device_bytes()
-        line = {
-            "metric": "Mrays/s (whole node) at 1080p 4-bounce", "value": round(value, 2), "unit": "Mrays/s", "n_gpus": world,
-            "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(ms_per_step, 4), "higher_is_better": True, "scaling": "weak",
-            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": (f"C1: the reference's default BVH scene ({view.num.triangleNum} triangles + spheres, discs, cylinders, cones), " if c1 else
-                                    f"C3: Pool demo scene ({view.num.triangleNum} triangles, water at rest), Pool shader variant, " if c3 else
-                                    f"C2: Stanford bunny x{a.subdivisions} subdivisions{f', {a.grid}x{a.grid} copies' if a.grid > 1 else ''} ({view.num.triangleNum} triangles) + ground disc + 1 light, ") +
-                                   f"{W}x{H}, {a.spp} spp per GPU, RayTraceDepth {a.depth}" + (", diffuse bounces (Philox, cosine-weighted)" if a.diffuse else ""),
-                       "bvh_builder": a.builder, "bvh_nodes": info["nodes"], "bvh_depth": info["max_depth"], "arithmetic": a.mode,
-                       "parallelism": f"replicated scene, {a.spp} sample indices per GPU, RCCL all-reduce of the image" if world > 1 else "1 GPU",
-                       "rays_per_frame": int(rays), "host_scene_build_s": round(build_s, 2), "scene_upload_s": round(upload_s, 2),
-                       "device_scene_bytes": dbytes},
-            "roofline": {"bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-                         "frac": round(achieved / HBM_PEAK_GBPS, 5), "traffic": traffic, "kernel_ms": round(kernel_ms, 4),
-                         "kernel": "trace kernels of one frame (wfTraceLeanKernel + wfTraceGroupKernel)" if a.mode == "fast" else "trace kernels of one frame (wfTraceKernel)",
-                         "launches_per_frame": trace_launches // TRACE_FRAMES, "frame_ms": round(frame_ms, 4),
-                         "frame_frac": round(alg_bytes / (frame_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS, 5),
-                         "algorithmic_bytes_per_frame": int(alg_bytes),
-                         "counts": {"node_visits": int(cn.nodeVisits), "tri_tests": int(cn.triTests), "sphere_tests": int(cn.sphereTests),
-                                    "other_tests": int(cn.otherTests), "rays": int(rays)}},
-        }
-        if not a.no_cpu_baseline and world == 1:
-            line["cpu_baseline"] = cpu_baseline(a, m, view, trans, W, H, variant)
-        print(json.dumps(line), flush=True)
+    if rank != 0:
+        wl.tr.close()
+        return
+    ms_per_step = elapsed / steps * 1e3
+    value = rays_all * steps / elapsed / 1e6
+    frame_ms = frame_ms_total / max(frames, 1)
+    traffic = None
+    if world == 1 and a.workload == "c2" and not a.tuning:
+        traffic = load_traffic("r02_traffic.json", {"workload_triangles": int(wl.view.num.triangleNum), "mode": a.mode, "builder": wl.builder,
+                                                    "width": W, "height": H, "spp": wl.spp, "depth": wl.depth, "diffuse": wl.diffuse})
     if world > 1:
-        dist.barrier()
-        dist.destroy_process_group()
-    tr.close()
+        par = (f"replicated scene, {wl.spp} sample indices per GPU, RCCL all-reduce of the image" + (" overlapping the next frame" if overlap else "")
+               if scaling == "weak" else "replicated scene, interleaved 16-row stripes per GPU, RCCL all-gather of the frame")
+    else:
+        par = "1 GPU"
+    line = {
+        "metric": "Mrays/s (whole node) at 1080p 4-bounce", "value": round(value, 2), "unit": "Mrays/s", "n_gpus": world,
+        "steps": steps, "warmup": warmup, "ms_per_step": round(ms_per_step, 4), "higher_is_better": True, "scaling": scaling,
+        "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "config": {"workload": wl.describe(), "bvh_builder": wl.builder, "bvh_nodes": wl.info["bvhNodes"], "bvh_depth": wl.info["bvhDepth"],
+                   "bvh_wide_depth": wl.info["wideDepth"], "arithmetic": a.mode, "parallelism": par,
+                   "rays_per_frame": int(rays_all), "host_scene_build_s": round(wl.build_s, 2), "scene_upload_s": round(wl.upload_s, 2),
+                   "device_scene_bytes": wl.tr.scene_device_bytes(),
+                   "schedule": {k: rinfo[k] for k in ("passes", "batch", "iterations", "compactFrom", "groupLanes", "frontierEntries", "contSlots")}},
+        "roofline": wl.roofline(kernel_ms, launches, frame_ms, traffic),
+    }
+    if not a.no_cpu_baseline and world == 1:
+        line["cpu_baseline"] = cpu_baseline(a, wl)
+    wl.tr.close()
+    if world == 1 and a.workload == "c2" and not a.no_c5 and not a.tuning and not a.grid:
+        line["roofline_c5"] = roofline_c5(a, local_rank, torch, dev)
+    print(json.dumps(line), flush=True)
 
 
-def cpu_baseline(a, m, view, trans, W, H, variant):
-    """The CPU oracle (C++ restatement of the reference shader, OpenMP over rows) on a bounded stripe of the SAME frame."""
+def roofline_c5(a, local_rank, torch, dev):
+    """SURVEY 8d's C5 on this GPU, timed by this run: the configuration the memory roofline is judged on."""
+    import copy
+    b = copy.copy(a)
+    b.width = b.height = b.depth = b.spp = b.grid = 0
+    b.builder, b.diffuse, b.tuning = "", False, ""
+    wl = Workload(b, "c5", local_rank, 1, 0, "weak")
+    wl.count()
+    out = torch.empty((wl.H, wl.W, 4), dtype=torch.float32, device=dev)
+    for _ in range(2):
+        wl.render_into(out.data_ptr())
+    wl.tr.sync()
+    wl.tr.timing_begin()
+    t0 = time.perf_counter()
+    steps = 4
+    for _ in range(steps):
+        wl.render_into(out.data_ptr())
+    wl.tr.sync()
+    elapsed = time.perf_counter() - t0
+    frame_ms_total, frames = wl.tr.timing_end()
+    kernel_ms, launches = wl.trace_kernel_ms(out.data_ptr(), 1)
+    traffic = load_traffic("r02_traffic_c5.json", {"workload_triangles": int(wl.view.num.triangleNum), "spp": wl.spp, "depth": wl.depth})
+    r = wl.roofline(kernel_ms, launches, frame_ms_total / max(frames, 1), traffic)
+    r.update({"workload": wl.describe(), "bvh_builder": wl.builder, "bvh_depth": wl.info["bvhDepth"], "bvh_wide_depth": wl.info["wideDepth"],
+              "Mrays_per_s": round(wl.rays * steps / elapsed / 1e6, 2), "ms_per_frame": round(elapsed / steps * 1e3, 3), "steps": steps,
+              "rays_per_frame": int(wl.rays), "host_scene_build_s": round(wl.build_s, 2), "scene_upload_and_build_s": round(wl.upload_s, 2),
+              "device_scene_bytes": wl.tr.scene_device_bytes()})
+    wl.tr.close()
+    return r
+
+
+def cpu_baseline(a, wl):
+    """The CPU oracle (C++ restatement of the reference shader, OpenMP over rows) on a bounded stripe of the SAME frame, plus the
+    recorded llvmpipe run of the reference's own shaders on C1 (it cannot run on the GPU box: /root/reference does not travel)."""
     from oracle import oracle_api as O
-    cores = min(16, os.cpu_count() or 1)
+    cores = os.cpu_count() or 1
+    try:
+        cores = len(os.sched_getaffinity(0))
+    except AttributeError:
+        pass
+    threads = int(os.environ.get("OMP_NUM_THREADS", "0")) or min(16, cores)      # the GPU box sets OMP_NUM_THREADS to its CPU share (16)
+    if wl.builder == "device":
+        if wl.view.num.triangleNum > 4_000_000:
+            return {"value": None, "note": "skipped: the oracle needs a host-built tree, minutes of work at this size"}
+        wl.model.data_init("median")          # the oracle walks a host-built tree: the image does not depend on the tree
+    H, W = wl.H, wl.W
     rows = a.cpu_rows or H
     r0 = max(0, (H - rows) // 2)
     # repeat the stripe until ~12 s of CPU work have been timed (at least twice)
     rays, dt, reps = 0, 0.0, 0
     while dt < 12.0 or reps < 2:
         t0 = time.perf_counter()
-        _, _, c = O.render(view, trans, W, H, max_depth=a.depth, variant=variant, rows=(r0, r0 + rows), threads=cores, want_hits=False, diffuse=a.diffuse)
+        _, _, c = O.render(wl.view if wl.builder != "device" else wl.model.scene_view(), wl.trans, W, H, max_depth=wl.depth, variant=wl.variant,
+                           rows=(r0, r0 + rows), threads=threads, want_hits=False, diffuse=wl.diffuse)
         dt += time.perf_counter() - t0
         rays += c.rays
         reps += 1
         if reps >= 200:
             break
-    return {"value": round(rays / dt / 1e6, 3), "unit": "Mrays/s", "cores": cores, "kind": "port",
-            "sample": f"rows {r0}..{r0 + rows} of the same {W}x{H} frame (one sample per pixel) rendered {reps} times ({rays} rays, {dt:.1f} s), "
-                      f"oracle/liboracle.so, OpenMP over rows"}
+    out = {"value": round(rays / dt / 1e6, 3), "unit": "Mrays/s", "cores": threads, "host_cpus_visible": cores, "kind": "port",
+           "sample": f"rows {r0}..{r0 + rows} of the same {W}x{H} frame (one sample per pixel) rendered {reps} times ({rays} rays, {dt:.1f} s), "
+                     f"oracle/liboracle.so, OpenMP over rows, {threads} threads"}
+    p = os.path.join(REPO, "profiles", "r02_baseline_llvmpipe_c1.json")
+    if os.path.exists(p):
+        b1 = json.load(open(p))
+        out["llvmpipe"] = {"note": "static record, measured once in the build container (tools/baseline_llvmpipe.py): the reference's own GLSL on "
+                                   "Mesa llvmpipe, C1 (BASELINE configs[0]); not timed by this run",
+                           "config": b1["config"], "host": b1["host"], "LP_NUM_THREADS": b1["LP_NUM_THREADS"], "runs": b1["runs"]}
+    return out
 
 
 if __name__ == "__main__":

@@ -70,6 +70,9 @@ enum LrlStatus {
                                   /* trace + one shade launch per ray segment                                        */
 #define LRL_FLAG_TIME_KERNELS 8u  /* between lrl_timing_begin/_end: time every trace-kernel launch on its own instead */
                                   /* of the frame as a whole (adds event records between the launches)               */
+#define LRL_FLAG_COUNT_FETCHES 32u /* FAST mode: run the FAST trace kernels themselves in a counting instantiation (ray counters + */
+                                  /* LrlCounters.recordFetches; node / primitive-test counts stay 0: LRL_FLAG_COUNTERS counts those  */
+                                  /* in the reference's visit order).  Slower: for the roofline's byte count, not for timing         */
 #define LRL_FLAG_DIFFUSE_BOUNCE 16u /* SURVEY 8d, C5 (no counterpart in the reference's shader, whose a11 step            */
                                   /* `RendererFragment0.cpp:718-740` always mirrors): the ray that continues after a   */
                                   /* hit takes a cosine-weighted direction about the normal on the incoming side, so    */
@@ -111,14 +114,26 @@ typedef struct LrlRenderParams {
                                  /* shear of `trans` described in SURVEY §8d                                 */
     uint32_t     rowBegin, rowEnd; /* render rows [rowBegin,rowEnd); 0,0 = whole frame (multi-GPU stripes)   */
     uint32_t     sampleBegin, sampleEnd; /* samples [begin,end) of the jitter table; 0,0 = all; the output   */
-                                 /* is then the SUM over that range divided by spp (partial means add up)    */
+                                 /* is then the SUM over that range divided by spp (partial means add up;    */
+                                 /* alpha = the range's share of spp, so the partial alphas add up to 1)     */
+    uint32_t     rowInterleave, rowShard; /* rowInterleave = N > 1 (with rowBegin = rowEnd = 0): the frame is cut  */
+                                 /* into stripes of LRL_STRIPE_ROWS rows and this render covers the stripes    */
+                                 /* s = rowShard (mod N), one after the other in its output (lrl_shard_rows    */
+                                 /* rows): the N shards of a frame balance its load and are all-gathered by    */
+                                 /* the caller (multi-GPU strong scaling).  0 or 1: rowBegin / rowEnd apply.   */
+                                 /* Not with LRL_FLAG_MEGAKERNEL.                                             */
 } LrlRenderParams;
+#define LRL_STRIPE_ROWS 16u
+/* rows of shard `shard` of `interleave` of a frame `height` rows high */
+uint32_t lrl_shard_rows(uint32_t height, uint32_t interleave, uint32_t shard);
 
 typedef struct LrlCounters {
     uint64_t raysPrimary, raysReflect, raysRefract, raysShadow;
     uint64_t nodeVisits;         /* box tests (one per node visit, closest-hit + any-hit traversals)         */
     uint64_t triTests, sphereTests, otherTests;
     uint64_t primaryHits;
+    uint64_t recordFetches;      /* LRL_FLAG_COUNT_FETCHES: 64-B records (four-wide nodes, triangle hot      */
+                                 /* records) the FAST trace kernels fetched; 0 otherwise                      */
 } LrlCounters;
 
 /* Scheduling knobs of the FAST-mode pipeline (no counterpart in the reference, whose driver schedules its fragment shader).
@@ -222,6 +237,28 @@ int lrl_water_init(LrlContext* ctx, uint32_t gx, uint32_t gy, float k, float dt,
                    uint32_t firstTriangle, const LrlTriangle* triangles);
 int lrl_water_step(LrlContext* ctx, uint32_t substeps);
 int lrl_water_read(LrlContext* ctx, LrlWaterPoint* points, LrlTriangle* triangles);
+
+/* what the library holds / did, for reports and tests */
+typedef struct LrlSceneInfo {
+    uint32_t bvhNodes;       /* nodes of the binary tree (the caller's, or 2 n - 1 of the device-built one)               */
+    uint32_t bvhRecords;     /* 64-B inner-node records (and four-wide node slots)                                        */
+    uint32_t bvhDepth;       /* depth of the binary tree                                                                   */
+    uint32_t wideDepth;      /* depth of the four-wide tree                                                                */
+    uint32_t deviceBuilt;    /* 1: built by the library on the device                                                      */
+    uint32_t materials;      /* distinct Color records                                                                     */
+} LrlSceneInfo;
+int lrl_scene_info(const LrlContext* ctx, LrlSceneInfo* out);
+typedef struct LrlRenderInfo {       /* of the last wavefront-pipeline render */
+    uint32_t iterations;     /* trace + shade rounds, summed over the passes                                               */
+    uint32_t passes;         /* generate ... accumulate passes (batches of samples)                                        */
+    uint32_t batch;          /* samples per full pass                                                                      */
+    uint32_t compactFrom;    /* first segment traced from compacted lists (0: none)                                        */
+    uint32_t groupLanes;     /* lanes per handed-over ray actually used (64: a wave per ray)                               */
+    uint32_t frontierEntries;/* frontier entries per handed-over ray (256 or 512)                                          */
+    uint32_t contSlots, contStride;
+    uint32_t handoverTrips[8]; /* thresholds of the first eight segments as the last pass used them (0: no hand-over)      */
+} LrlRenderInfo;
+int lrl_last_render_info(const LrlContext* ctx, LrlRenderInfo* out);
 
 /* device memory held for the scene (bytes), by class: nodes (binary records + four-wide nodes), triangle hot,
  * triangle cold, other */

@@ -28,10 +28,11 @@ for _dt, _sz in ((COLOR, 80), (BVHNODE, 64), (TRIANGLE, 160), (TRIANGLE_GPU, 176
                  (CONE, 128), (POINTLIGHT, 32), (TRANS, 64), (DECAY_ORIGIN, 144)):
     assert _dt.itemsize == _sz, (_dt, _dt.itemsize, _sz)
 
+STRIPE_ROWS = 16          # LRL_STRIPE_ROWS
 GEOM_TRIANGLE, GEOM_SPHERE, GEOM_CIRCLE, GEOM_CYLINDER, GEOM_CONE = 2, 3, 4, 5, 6
 VARIANT_BVH, VARIANT_POOL = 0, 1
 MODE_PARITY, MODE_FAST = 0, 1
-FLAG_COUNTERS, FLAG_OUT_DEVICE, FLAG_MEGAKERNEL, FLAG_TIME_KERNELS, FLAG_DIFFUSE_BOUNCE = 1, 2, 4, 8, 16
+FLAG_COUNTERS, FLAG_OUT_DEVICE, FLAG_MEGAKERNEL, FLAG_TIME_KERNELS, FLAG_DIFFUSE_BOUNCE, FLAG_COUNT_FETCHES = 1, 2, 4, 8, 16, 32
 
 
 def color(r=0.0, t=0.0, d=0.0, g=0.0, decay=0.0, n=1.0, texR=-1, texT=-1, texD=-1, texG=-1):
@@ -57,7 +58,7 @@ class SceneView(C.Structure):
 class RenderParams(C.Structure):
     _fields_ = [("maxDepth", C.c_uint32), ("variant", C.c_uint32), ("mode", C.c_uint32), ("flags", C.c_uint32), ("spp", C.c_uint32),
                 ("jitter", C.POINTER(C.c_float)), ("rowBegin", C.c_uint32), ("rowEnd", C.c_uint32), ("sampleBegin", C.c_uint32),
-                ("sampleEnd", C.c_uint32)]
+                ("sampleEnd", C.c_uint32), ("rowInterleave", C.c_uint32), ("rowShard", C.c_uint32)]
 
 
 class Tuning(C.Structure):
@@ -68,9 +69,18 @@ class Tuning(C.Structure):
                 ("debug", C.c_uint32)]
 
 
+class SceneInfo(C.Structure):
+    _fields_ = [(n, C.c_uint32) for n in ("bvhNodes", "bvhRecords", "bvhDepth", "wideDepth", "deviceBuilt", "materials")]
+
+
+class RenderInfo(C.Structure):
+    _fields_ = [(n, C.c_uint32) for n in ("iterations", "passes", "batch", "compactFrom", "groupLanes", "frontierEntries", "contSlots",
+                                          "contStride")] + [("handoverTrips", C.c_uint32 * 8)]
+
+
 class Counters(C.Structure):
     _fields_ = [(n, C.c_uint64) for n in ("raysPrimary", "raysReflect", "raysRefract", "raysShadow", "nodeVisits", "triTests",
-                                          "sphereTests", "otherTests", "primaryHits")]
+                                          "sphereTests", "otherTests", "primaryHits", "recordFetches")]
 
     def as_dict(self):
         return {n: int(getattr(self, n)) for n, _ in self._fields_}

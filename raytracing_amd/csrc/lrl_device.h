@@ -74,6 +74,9 @@ struct KFrame {
     const LrlTrans* trans;   // device array, one per sample (jitter shear already applied)
     uint32_t width, height;
     uint32_t rowBegin, rowEnd;
+    uint32_t rows;                     // rows of this render's output (rowEnd - rowBegin, or the rows of the shard's stripes)
+    uint32_t interleave, shard;        // > 1: this render covers the stripes s = shard (mod interleave) of LRL_STRIPE_ROWS rows (wavefront pipeline)
+    float alpha;                       // alpha of the output: the share of the frame's samples this render sums (1 for all of them)
     uint32_t sampleBegin, sampleEnd;   // samples rendered by this launch
     uint32_t spp;                      // divisor of the mean
     uint32_t maxDepth;
@@ -83,7 +86,7 @@ struct KFrame {
 };
 
 enum { LRL_CTR_PRIMARY = 0, LRL_CTR_REFLECT, LRL_CTR_REFRACT, LRL_CTR_SHADOW, LRL_CTR_NODES, LRL_CTR_TRI, LRL_CTR_SPH,
-       LRL_CTR_OTHER, LRL_CTR_PRIMARY_HITS, LRL_CTR_COUNT };
+       LRL_CTR_OTHER, LRL_CTR_PRIMARY_HITS, LRL_CTR_FETCH, LRL_CTR_COUNT };
 
 #ifndef LRL_BLOCK_THREADS
 #define LRL_BLOCK_THREADS 256

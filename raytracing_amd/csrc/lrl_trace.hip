@@ -86,6 +86,7 @@ struct LrlContext {
     hipStream_t lastRenderStream = nullptr;
     bool renderedOnce = false;
     LrlTuning tuning{};
+    LrlRenderInfo renderInfo{};
     void* noallocScratch = nullptr;     // this device's copy of the static staging array (lrl_scene_update_triangles_noalloc)
     std::vector<uint32_t> noallocMat;   // LRL_NOALLOC_MAX_TRIANGLES material indices, allocated in lrl_create
     std::vector<float> workPerRay;      // per iteration: frontier entries per handed-over ray, last feedback
@@ -918,7 +919,7 @@ static int renderWavefront(LrlContext* c, const LrlRenderParams* p, const KScene
     // Trace kernel per iteration.  PARITY and counting renders: wfTraceKernel (the reference's visit order).  FAST: the lean
     // one-lane-per-ray kernel over the four-wide tree, which hands rays that are still going after handoverTrips trips to the
     // lanes-per-ray kernel.
-    const bool special = fast && !ctr && !tn.traceRef;
+    const bool special = fast && !tn.traceRef && (!ctr || (p->flags & LRL_FLAG_COUNT_FETCHES));
     // deepest stack: one parked child per level of the binary tree (wfTraceKernel), three per level of the four-wide tree (lean)
     const uint32_t stackNeed = special ? std::max(c->bvhDepth + 1, 3 * c->node4Depth + 4) : c->bvhDepth + 1;
     const uint32_t ldsRows = special ? uint32_t(LRL_LEAN_STACK) : uint32_t(LRL_WF_STACK);
@@ -1126,6 +1127,14 @@ static int renderWavefront(LrlContext* c, const LrlRenderParams* p, const KScene
     }
     if (e1) CRUMB_TRY(c, "hipEventRecord(frame end)", hipEventRecord(e1, stream));
     c->lastIterations = iterations;
+    LrlRenderInfo& ri = c->renderInfo;
+    ri = LrlRenderInfo{};
+    ri.iterations = iterations; ri.passes = passIndex; ri.batch = batch;
+    if (special) {
+        ri.compactFrom = compactFrom; ri.groupLanes = swarmGroup; ri.frontierEntries = swarmGroup == 64 ? LRL_SWARM_CAP : groupCap;
+        ri.contSlots = contSlots; ri.contStride = contStride;
+        for (uint32_t i = 0; i < 8; ++i) ri.handoverTrips[i] = handoverFits ? c->handoverThr[i] : 0u;
+    }
     return LRL_OK;
 }
 
@@ -1159,7 +1168,7 @@ static int renderImpl(LrlContext* c, const LrlRenderParams* p, float* rgbaDev, u
         c->transUploaded = tr;
     }
     unsigned long long* ctr = nullptr;
-    if (p->flags & LRL_FLAG_COUNTERS) {
+    if (p->flags & (LRL_FLAG_COUNTERS | LRL_FLAG_COUNT_FETCHES)) {
         if ((rc = ensure(c, c->counterDev, LRL_CTR_COUNT * 8))) return rc;
         HIP_TRY(c, hipMemsetAsync(c->counterDev.p, 0, LRL_CTR_COUNT * 8, stream));
         ctr = static_cast<unsigned long long*>(c->counterDev.p);
@@ -1170,6 +1179,11 @@ static int renderImpl(LrlContext* c, const LrlRenderParams* p, float* rgbaDev, u
     f.trans = static_cast<const LrlTrans*>(c->transDev.p);
     f.width = c->width; f.height = c->height;
     f.rowBegin = p->rowBegin; f.rowEnd = p->rowBegin + rows;
+    f.rows = rows;
+    f.interleave = p->rowInterleave > 1 ? p->rowInterleave : 0u;
+    f.shard = f.interleave ? p->rowShard : 0u;
+    if (f.interleave) { f.rowBegin = 0; f.rowEnd = c->height; }
+    f.alpha = float(s1 - s0) / float(spp);      // 1 exactly for a whole frame
     f.sampleBegin = s0; f.sampleEnd = s1; f.spp = spp;
     f.maxDepth = p->maxDepth;
     f.stackEntries = std::min(c->bvhDepth + 1, LRL_LDS_STACK_ENTRIES);
@@ -1234,14 +1248,36 @@ static int checkRender(LrlContext* c, const LrlRenderParams* p, uint32_t& rows) 
     if (!c->haveScene || !c->haveCamera) return fail(c, LRL_ERR_NO_SCENE, "scene and camera must be set before rendering");
     if (p->maxDepth < 1 || p->maxDepth > LRL_MAX_RAY_DEPTH) return fail(c, LRL_ERR_LIMIT, "maxDepth must be 1..LRL_MAX_RAY_DEPTH");
     if (p->variant > LRL_VARIANT_POOL || p->mode > LRL_MODE_FAST) return fail(c, LRL_ERR_INVALID_ARG, "unknown variant / mode");
+    if ((p->flags & LRL_FLAG_COUNT_FETCHES) && (p->mode != LRL_MODE_FAST || (p->flags & (LRL_FLAG_COUNTERS | LRL_FLAG_MEGAKERNEL))))
+        return fail(c, LRL_ERR_INVALID_ARG, "LRL_FLAG_COUNT_FETCHES goes with LRL_MODE_FAST, without LRL_FLAG_COUNTERS / LRL_FLAG_MEGAKERNEL");
     if (p->spp < 1 || p->spp > LRL_MAX_SPP) return fail(c, LRL_ERR_LIMIT, "spp must be 1..LRL_MAX_SPP");
     uint32_t r0 = p->rowBegin, r1 = p->rowEnd;
     if (r0 == 0 && r1 == 0) r1 = c->height;
     if (r0 >= r1 || r1 > c->height) return fail(c, LRL_ERR_INVALID_ARG, "row range invalid");
+    if (p->rowInterleave > 1) {
+        if (p->rowBegin || p->rowEnd) return fail(c, LRL_ERR_INVALID_ARG, "rowInterleave goes with rowBegin = rowEnd = 0");
+        if (p->rowShard >= p->rowInterleave) return fail(c, LRL_ERR_INVALID_ARG, "rowShard must be below rowInterleave");
+        if (p->flags & LRL_FLAG_MEGAKERNEL) return fail(c, LRL_ERR_INVALID_ARG, "rowInterleave is implemented in the wavefront pipeline only");
+        r0 = 0;
+        r1 = lrl_shard_rows(c->height, p->rowInterleave, p->rowShard);
+        if (r1 == 0) return fail(c, LRL_ERR_INVALID_ARG, "this shard holds no rows of the frame (more shards than stripes)");
+    }
     if (!(p->sampleBegin == 0 && p->sampleEnd == 0) && (p->sampleBegin >= p->sampleEnd || p->sampleEnd > p->spp))
         return fail(c, LRL_ERR_INVALID_ARG, "sample range invalid");
     rows = r1 - r0;
     return LRL_OK;
+}
+
+uint32_t lrl_shard_rows(uint32_t height, uint32_t interleave, uint32_t shard) {
+    if (interleave <= 1) return shard == 0 ? height : 0u;
+    if (shard >= interleave) return 0u;
+    const uint32_t stripes = (height + LRL_STRIPE_ROWS - 1) / LRL_STRIPE_ROWS;
+    if (shard >= stripes) return 0u;
+    const uint32_t mine = (stripes - shard + interleave - 1) / interleave;      // stripes shard, shard + N, ...
+    const uint32_t last = shard + (mine - 1) * interleave;                      // this shard's last stripe
+    uint32_t rows = mine * LRL_STRIPE_ROWS;
+    if (last == stripes - 1) rows -= stripes * LRL_STRIPE_ROWS - height;       // the frame's last stripe may be short
+    return rows;
 }
 
 int lrl_render_async(LrlContext* c, const LrlRenderParams* p, float* rgbaDev, uint32_t* hitDev, void* hipStream) {
@@ -1292,13 +1328,14 @@ int lrl_render(LrlContext* c, const LrlRenderParams* p, float* rgba, uint32_t* h
         if (hit) HIP_TRY(c, hipMemcpyAsync(hit, h, px * 8, hipMemcpyDeviceToHost, c->stream));
     }
     HIP_TRY(c, hipStreamSynchronize(c->stream));
-    if (p->flags & LRL_FLAG_COUNTERS) {
+    if (p->flags & (LRL_FLAG_COUNTERS | LRL_FLAG_COUNT_FETCHES)) {
         unsigned long long v[LRL_CTR_COUNT];
         HIP_TRY(c, hipMemcpy(v, c->counterDev.p, sizeof(v), hipMemcpyDeviceToHost));
         c->counters.raysPrimary = v[LRL_CTR_PRIMARY]; c->counters.raysReflect = v[LRL_CTR_REFLECT];
         c->counters.raysRefract = v[LRL_CTR_REFRACT]; c->counters.raysShadow = v[LRL_CTR_SHADOW];
         c->counters.nodeVisits = v[LRL_CTR_NODES]; c->counters.triTests = v[LRL_CTR_TRI]; c->counters.sphereTests = v[LRL_CTR_SPH];
         c->counters.otherTests = v[LRL_CTR_OTHER]; c->counters.primaryHits = v[LRL_CTR_PRIMARY_HITS];
+        c->counters.recordFetches = v[LRL_CTR_FETCH];
     }
     return LRL_OK;
 }
@@ -1407,6 +1444,20 @@ int lrl_water_read(LrlContext* c, LrlWaterPoint* points, LrlTriangle* triangles)
     HIP_TRY(c, hipStreamSynchronize(c->stream));
     if (points) HIP_TRY(c, hipMemcpy(points, c->waterPoints.p, size_t(c->waterGX) * c->waterGY * sizeof(LrlWaterPoint), hipMemcpyDeviceToHost));
     if (triangles) HIP_TRY(c, hipMemcpy(triangles, c->waterTris.p, size_t(2) * (c->waterGX - 1) * (c->waterGY - 1) * sizeof(LrlTriangle), hipMemcpyDeviceToHost));
+    return LRL_OK;
+}
+
+int lrl_scene_info(const LrlContext* c, LrlSceneInfo* out) {
+    if (!c || !out) return LRL_ERR_INVALID_ARG;
+    if (!c->haveScene) return LRL_ERR_NO_SCENE;
+    out->bvhNodes = c->nodeNum; out->bvhRecords = c->recNum; out->bvhDepth = c->bvhDepth; out->wideDepth = c->node4Depth;
+    out->deviceBuilt = c->deviceBuilt ? 1u : 0u; out->materials = uint32_t(c->materialTable.size());
+    return LRL_OK;
+}
+
+int lrl_last_render_info(const LrlContext* c, LrlRenderInfo* out) {
+    if (!c || !out) return LRL_ERR_INVALID_ARG;
+    *out = c->renderInfo;
     return LRL_OK;
 }
 

@@ -3,6 +3,9 @@ samples are independent, so the only exchange step is combining the per-rank ima
 
   * row stripes   — rank r renders interleaved stripes of `stripe` rows; parts are all-gathered and
                     interleaved back.  Bit-identical to the single-GPU frame.
+  * interleaved   — the same stripes rendered by ONE call per rank (LrlRenderParams.rowInterleave / rowShard: the rank's
+                    stripes come back concatenated), all-gathered with one collective and un-interleaved with one
+                    index_select.  Bit-identical to the single-GPU frame; this is the strong-scaling path of bench.py.
   * sample ranges — rank r renders samples [s0, s1) of the jitter table for the whole frame; each part
                     is already divided by the total spp, so an all-reduce(SUM) gives the mean.
 
@@ -61,3 +64,41 @@ def render_samples(render, spp, height, width, world, rank, device="cpu"):
     if world > 1:
         dist.all_reduce(part, op=dist.ReduceOp.SUM)
     return part
+
+
+STRIPE_ROWS = 16      # LRL_STRIPE_ROWS (include/lrl_trace.h)
+
+
+def shard_rows(height, world, rank, stripe=STRIPE_ROWS):
+    """Rows of rank's interleaved shard (== lrl_shard_rows)."""
+    return sum(r1 - r0 for r0, r1 in stripes(height, world, rank, stripe))
+
+
+def interleave_index(height, world, stripe=STRIPE_ROWS):
+    """For every row of the frame, its row in the all-gathered buffer [world * pad, W, 4] (pad = the largest shard)."""
+    pad = max(shard_rows(height, world, k, stripe) for k in range(world))
+    idx = torch.empty(height, dtype=torch.long)
+    for k in range(world):
+        o = 0
+        for r0, r1 in stripes(height, world, k, stripe):
+            idx[r0:r1] = torch.arange(k * pad + o, k * pad + o + (r1 - r0))
+            o += r1 - r0
+    return idx, pad
+
+
+def render_interleaved(render, height, width, world, rank, device="cpu", index=None):
+    """Every rank returns the full [H, W, 4] frame.  render(rows=("interleave", world, rank)) -> this rank's stripes, concatenated,
+    as a tensor [shard_rows, W, 4] on `device` (or writes into the buffer handed to it: render(rows=..., out=buf))."""
+    if index is None:
+        index = interleave_index(height, world)
+    idx, pad = index
+    mine = shard_rows(height, world, rank)
+    buf = torch.zeros((pad, width, 4), dtype=torch.float32, device=device)
+    if mine:
+        buf[:mine] = render(rows=("interleave", world, rank))
+    if world > 1:
+        full = torch.empty((world * pad, width, 4), dtype=torch.float32, device=device)
+        dist.all_gather_into_tensor(full, buf)
+    else:
+        full = buf
+    return full.index_select(0, idx.to(full.device))

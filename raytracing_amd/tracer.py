@@ -20,7 +20,7 @@ EXPORTS = [
     "lrl_scene_read_triangles_gpu", "lrl_scene_read_circles", "lrl_set_camera", "lrl_set_decay_origin", "lrl_compute_decay_origin",
     "lrl_render", "lrl_render_async", "lrl_sync", "lrl_get_counters", "lrl_last_kernel_ms", "lrl_scene_device_bytes",
     "lrl_timing_begin", "lrl_timing_end", "lrl_water_init", "lrl_water_step", "lrl_water_read", "lrl_scene_rebuild_bvh", "lrl_quantize_rgba8", "lrl_get_tuning", "lrl_set_tuning",
-    "lrl_scene_update_triangles_noalloc",
+    "lrl_scene_update_triangles_noalloc", "lrl_shard_rows", "lrl_scene_info", "lrl_last_render_info",
 ]
 
 
@@ -55,6 +55,10 @@ def lib():
         L.lrl_scene_rebuild_bvh.argtypes = [C.c_void_p]
         L.lrl_quantize_rgba8.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64]
         L.lrl_water_read.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
+        L.lrl_shard_rows.argtypes = [C.c_uint32, C.c_uint32, C.c_uint32]
+        L.lrl_shard_rows.restype = C.c_uint32
+        L.lrl_scene_info.argtypes = [C.c_void_p, C.POINTER(abi.SceneInfo)]
+        L.lrl_last_render_info.argtypes = [C.c_void_p, C.POINTER(abi.RenderInfo)]
         L.lrl_get_tuning.argtypes = [C.c_void_p, C.POINTER(abi.Tuning)]
         L.lrl_set_tuning.argtypes = [C.c_void_p, C.POINTER(abi.Tuning)]
         _lib = L
@@ -187,6 +191,10 @@ class Tracer:
         self._ck(self._L.lrl_compute_decay_origin(self._ctx, variant, out.ctypes.data_as(C.c_void_p)))
         return out[0]
 
+    def shard_rows(self, interleave, shard):
+        """Rows of the output of a render with rows=("interleave", N, shard)."""
+        return int(self._L.lrl_shard_rows(self.height, interleave, shard))
+
     def _params(self, max_depth, variant, mode, flags, jitter, rows, samples):
         spp = 1
         jp = None
@@ -194,17 +202,27 @@ class Tracer:
             self._jit = np.ascontiguousarray(jitter, dtype=np.float32).reshape(-1, 2)
             spp = self._jit.shape[0]
             jp = self._jit.ctypes.data_as(C.POINTER(C.c_float))
+        il, sh = 0, 0
+        if rows and rows[0] == "interleave":          # ("interleave", N, shard): the stripes s = shard (mod N) of 16 rows
+            il, sh = int(rows[1]), int(rows[2])
+            rows = None
         r0, r1 = rows if rows else (0, 0)
         s0, s1 = samples if samples else (0, 0)
-        return abi.RenderParams(max_depth, variant, mode, flags, spp, jp, r0, r1, s0, s1)
+        return abi.RenderParams(max_depth, variant, mode, flags, spp, jp, r0, r1, s0, s1, il, sh)
+
+    def _nrows(self, rows):
+        if rows and rows[0] == "interleave":
+            return self.shard_rows(rows[1], rows[2])
+        return (rows[1] - rows[0]) if rows else self.height
 
     def render(self, max_depth=10, variant=abi.VARIANT_BVH, mode=abi.MODE_PARITY, counters=False, jitter=None, rows=None,
-               samples=None, want_hits=True, megakernel=False, diffuse=False):
+               samples=None, want_hits=True, megakernel=False, diffuse=False, count_fetches=False):
         """-> (rgba [rows, W, 4] float32, hits [rows, W, 2] uint32 or None).  megakernel=True: the one-launch schedule;
         diffuse=True: LRL_FLAG_DIFFUSE_BOUNCE (cosine-weighted continuation rays)."""
-        flags = (abi.FLAG_COUNTERS if counters else 0) | (abi.FLAG_MEGAKERNEL if megakernel else 0) | (abi.FLAG_DIFFUSE_BOUNCE if diffuse else 0)
+        flags = ((abi.FLAG_COUNTERS if counters else 0) | (abi.FLAG_MEGAKERNEL if megakernel else 0) | (abi.FLAG_DIFFUSE_BOUNCE if diffuse else 0)
+                 | (abi.FLAG_COUNT_FETCHES if count_fetches else 0))
         p = self._params(max_depth, variant, mode, flags, jitter, rows, samples)
-        nrows = (rows[1] - rows[0]) if rows else self.height
+        nrows = self._nrows(rows)
         img = np.zeros((nrows, self.width, 4), dtype=np.float32)
         hits = np.zeros((nrows, self.width, 2), dtype=np.uint32) if want_hits else None
         self._ck(self._L.lrl_render(self._ctx, C.byref(p), img.ctypes.data_as(C.c_void_p),
@@ -245,6 +263,18 @@ class Tracer:
         ms, n = C.c_double(), C.c_uint32()
         self._ck(self._L.lrl_timing_end(self._ctx, C.byref(ms), C.byref(n)))
         return float(ms.value), int(n.value)
+
+    def scene_info(self):
+        i = abi.SceneInfo()
+        self._ck(self._L.lrl_scene_info(self._ctx, C.byref(i)))
+        return {n: int(getattr(i, n)) for n, _ in i._fields_}
+
+    def last_render_info(self):
+        i = abi.RenderInfo()
+        self._ck(self._L.lrl_last_render_info(self._ctx, C.byref(i)))
+        d = {n: int(getattr(i, n)) for n, _ in i._fields_ if n != "handoverTrips"}
+        d["handoverTrips"] = [int(x) for x in i.handoverTrips]
+        return d
 
     def scene_device_bytes(self):
         v = (C.c_uint64 * 4)()

@@ -789,3 +789,24 @@ def test_hit_ids_of_a_sample_range(tracer, default_model):
         _, h_zero = tracer.render(max_depth=6, jitter=jit[0:1], megakernel=mega)
         assert np.array_equal(h_range, h_single)
         assert not np.array_equal(h_range, h_zero)           # the jitter moves some edge pixels: the two samples differ
+
+
+@pytest.mark.parametrize("mode", [abi.MODE_PARITY, abi.MODE_FAST])
+def test_c1_at_1024_vs_llvmpipe_golden(tracer, default_model, mode):
+    """BASELINE configs[0] at its own size, 1024 x 1024, RayTraceDepth 10: primary-hit ids of every pixel and 16 x 16 tile sums of
+    the image against the reference's shaders on llvmpipe (tests/golden/bvh_viewA_1024.npz, tools/baseline_llvmpipe.py)."""
+    z = np.load(os.path.join(GOLDEN, "bvh_viewA_1024.npz"))
+    W = H = int(z["width"])
+    tr = np.frombuffer(z["trans"].tobytes(), dtype=abi.TRANS)
+    tracer.scene_upload(default_model.scene_view())
+    tracer.set_camera(tr, W, H)
+    tracer.set_decay_origin((0, 0, 0, 1))
+    img, hits = tracer.render(max_depth=int(z["depth"]), mode=mode)
+    same = ((hits[..., 0] == z["hit_type"]) & (hits[..., 1] == z["hit_idx"])).mean()
+    assert same >= ID_BAR, (mode, same)
+    T = int(z["tile"])
+    sums = np.nan_to_num(img[..., :3].astype(np.float64), nan=0.0, posinf=0.0, neginf=0.0).reshape(H // T, T, W // T, T, 3).sum(axis=(1, 3))
+    err = np.abs(sums - z["tile_sums"])
+    # a tile sum is 256 pixels: the per-pixel RMSE bars (1e-4 PARITY, 5e-3 FAST) times sqrt(256) for independent errors
+    bar = (RMSE_PARITY if mode == abi.MODE_PARITY else RMSE_FAST) * 16
+    assert np.sqrt((err ** 2).mean()) <= bar, (mode, float(np.sqrt((err ** 2).mean())), float(err.max()), same)

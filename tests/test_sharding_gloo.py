@@ -26,6 +26,20 @@ def test_sample_ranges_partition_samples():
             assert got == list(range(spp))
 
 
+def test_interleave_index_matches_the_stripes():
+    for H in (1, 16, 17, 135, 1080, 2160):
+        for world in (1, 2, 3, 8):
+            idx, pad = sharding.interleave_index(H, world)
+            assert pad == max(sharding.shard_rows(H, world, k) for k in range(world))
+            assert sum(sharding.shard_rows(H, world, k) for k in range(world)) == H
+            # gathering shard k's rows back through the index gives the rows the stripes name
+            rows = torch.full((world * pad,), -1, dtype=torch.long)
+            for k in range(world):
+                mine = [r for a, b in sharding.stripes(H, world, k) for r in range(a, b)]
+                rows[k * pad:k * pad + len(mine)] = torch.tensor(mine, dtype=torch.long)
+            assert torch.equal(rows[idx], torch.arange(H))
+
+
 def _free_port():
     with socket.socket() as s:
         s.bind(("127.0.0.1", 0))
@@ -58,11 +72,17 @@ def _worker(rank, world, port, q):
         return torch.from_numpy(acc / np.float32(spp))
 
     frame = sharding.render_rows(lambda rows: render_rows(rows), H, W, world, rank, stripe=16)
+
+    def render_shard(rows):                          # ("interleave", N, k): the oracle renders stripe by stripe
+        _, n, k = rows
+        return torch.cat([render_rows(r) for r in sharding.stripes(H, n, k)], dim=0)
+
+    frame2 = sharding.render_interleaved(render_shard, H, W, world, rank)
     mean = sharding.render_samples(lambda samples: render_samples(samples), spp, H, W, world, rank)
     if rank == 0:
         full, _, _ = O.render(view, tr, W, H, max_depth=6, want_hits=False)
         full_mean, _, _ = O.render(view, ts, W, H, max_depth=6, want_hits=False)
-        q.put((bool(np.array_equal(frame.numpy(), full)), float(np.abs(mean.numpy()[..., :3] - full_mean[..., :3]).max())))
+        q.put((bool(np.array_equal(frame.numpy(), full)) and bool(np.array_equal(frame2.numpy(), full)), float(np.abs(mean.numpy()[..., :3] - full_mean[..., :3]).max())))
     dist.barrier()
     dist.destroy_process_group()
 
