@@ -566,6 +566,7 @@ int lrl_set_tuning(LrlContext* c, const LrlTuning* t) {
     c->tuning = *t;
     c->handoverThr.clear();      // the adaptive thresholds start again from the new base values
     c->feedbackTick = 0;
+    c->contIters = 0;
     return LRL_OK;
 }
 
@@ -590,7 +591,7 @@ int lrl_destroy(LrlContext* c) {
 }
 
 int lrl_scene_upload(LrlContext* c, const LrlSceneView* s) {
-    if (c) { c->handoverThr.clear(); c->feedbackTick = 0; }      // the hand-over thresholds start again with a new scene
+    if (c) { c->handoverThr.clear(); c->feedbackTick = 0; c->contIters = 0; }      // the hand-over thresholds start again with a new scene (feedback still in flight is the old scene's: dropped)
     if (!c || !s) return LRL_ERR_INVALID_ARG;
     HIP_TRY(c, hipSetDevice(c->device));
     const LrlGeometryNum& g = s->num;

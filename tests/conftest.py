@@ -30,6 +30,37 @@ def load_golden(name):
     return g
 
 
+# ---- the bars (north_star: ids >= 99.99 %, image RMSE under a stated tolerance) ----
+ID_BAR = 0.9999
+RMSE_PARITY = 1e-4          # PARITY arithmetic = the reference's operation order; observed <= 1e-8 (expf differs in the last bit)
+# FAST arithmetic (hoisted reciprocals, fused multiply-add, rcp) moves a few rays at floating-point tie edges onto the neighbouring
+# primitive, and one such pixel can differ by 0.5: a plain RMSE bar is decided by a handful of pixels (observed 9 of 25 600 on the Pool's
+# view A: RMSE 5.8e-3).  So FAST is judged by three numbers: the share of pixels that moved by more than 1e-3 (observed <= 8e-4), the RMSE
+# over all other pixels (observed <= 2e-6) and a gross-error guard over all pixels.
+FAST_FRAC = 2e-3
+FAST_RMSE_TRIM = 2e-5
+FAST_RMSE = 2e-2
+OBSERVED = []               # (what, mode, stats) of every check, dumped at session end (gpurun_out/observed_bars.json)
+
+
+def check_image(img, ref, mode, what, frac_bar=None):
+    """Assert the image bar of `mode` (0 = PARITY, 1 = FAST) with the observed numbers in the message."""
+    st = image_stats(img, ref)
+    OBSERVED.append((str(what), int(mode), {k: st[k] for k in ("rmse", "rmse_trim", "frac_gt_1e-3", "max")}))
+    if mode == 0:
+        assert st["rmse"] <= RMSE_PARITY, (what, "PARITY", st)
+    else:
+        assert st["frac_gt_1e-3"] <= (frac_bar or FAST_FRAC) and st["rmse_trim"] <= FAST_RMSE_TRIM and st["rmse"] <= FAST_RMSE, (what, "FAST", st)
+    return st
+
+
+def pytest_sessionfinish(session, exitstatus):
+    if OBSERVED and os.path.isdir(os.path.join(REPO, "gpurun_out")):
+        import json
+        with open(os.path.join(REPO, "gpurun_out", "observed_bars.json"), "w") as f:
+            json.dump(OBSERVED, f, indent=0)
+
+
 def image_stats(a, b):
     """a, b: [H, W, >=3] float images -> dict(rmse, max, frac_gt, nonfinite_mismatch).
     Pixels that are non-finite in BOTH images are skipped (the reference's sphere uv is acos() of a ratio that
@@ -39,8 +70,11 @@ def image_stats(a, b):
     fa, fb = np.isfinite(a3).all(axis=-1), np.isfinite(b3).all(axis=-1)
     both = fa & fb
     d = (a3 - b3)[both]
+    big = np.abs(d).max(axis=-1) > 1e-3 if d.size else np.zeros(0, dtype=bool)
+    small = d[~big]
     st = {"rmse": float(np.sqrt(np.mean(d * d))) if d.size else 0.0, "max": float(np.abs(d).max()) if d.size else 0.0,
-          "frac_gt_1e-3": float((np.abs(d).max(axis=-1) > 1e-3).mean()) if d.size else 0.0,
+          "frac_gt_1e-3": float(big.mean()) if d.size else 0.0,
+          "rmse_trim": float(np.sqrt(np.mean(small * small))) if small.size else 0.0,      # over the pixels within 1e-3
           "nonfinite_mismatch": float((fa != fb).mean()), "nonfinite_both": float((~fa & ~fb).mean())}
     assert st["nonfinite_mismatch"] <= 1e-3, st
     return st

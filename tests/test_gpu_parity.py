@@ -1,9 +1,9 @@
 """GPU parity: the HIP path, called through the C ABI (liblrltrace.so), against
   (1) the golden vectors rendered by the reference's own shaders on llvmpipe, and
   (2) the CPU oracle on the same seeded inputs (random scenes, edge cases).
-Bars: primary-hit ids identical on >= 99.99 % of pixels; per-pixel RMSE <= 1e-4 in PARITY mode
-(expression order of the reference on llvmpipe; differences come from expf only) and <= 5e-3 in
-FAST mode (hoisted reciprocals + fused multiply-add; mismatches at floating-point tie edges).
+Bars (tests/conftest.py): primary-hit ids identical on >= 99.99 % of pixels; per-pixel RMSE <= 1e-4 in PARITY mode
+(expression order of the reference on llvmpipe; differences come from expf only); in FAST mode (hoisted reciprocals,
+fused multiply-add) at most 0.2 % of the pixels off by more than 1e-3 (floating-point tie edges) and RMSE <= 2e-5 over the rest.
 Ray / node-visit / primitive-test counters must equal the oracle's when the images agree.
 """
 import os
@@ -11,15 +11,12 @@ import os
 import numpy as np
 import pytest
 
-from conftest import GOLDEN, image_stats, load_golden
+from conftest import FAST_RMSE, GOLDEN, ID_BAR, RMSE_PARITY, check_image, image_stats, load_golden
 from oracle import oracle_api as O
 from raytracing_amd import abi, host, scenes
 
 pytestmark = pytest.mark.gpu
 
-ID_BAR = 0.9999
-RMSE_PARITY = 1e-4
-RMSE_FAST = 5e-3
 
 
 def run_golden(tracer, model, name, mode, jitter=None, decay=(0, 0, 0, 1), id_bar=ID_BAR):
@@ -29,9 +26,8 @@ def run_golden(tracer, model, name, mode, jitter=None, decay=(0, 0, 0, 1), id_ba
     tracer.set_decay_origin(decay)
     img, hits = tracer.render(max_depth=g["depth"], variant=g["variant"], mode=mode, jitter=jitter)
     same = (hits == g["ids"]).all(axis=-1).mean()
-    st = image_stats(img, g["rgb"])
     assert same >= id_bar, (name, mode, same)
-    assert st["rmse"] <= (RMSE_PARITY if mode == abi.MODE_PARITY else RMSE_FAST), (name, mode, st)
+    st = check_image(img, g["rgb"], mode, name)
     assert np.all(img[..., 3] == 1.0)
     return st
 
@@ -151,11 +147,11 @@ def test_random_scenes_vs_oracle(tracer, seed, builder):
     tracer.set_camera(tr, W, H)
     tracer.set_decay_origin((0, 0, 0, 1))
     oimg, ohits, cn = O.render(v, tr, W, H, max_depth=6, threads=8)
-    for mode, bar in ((abi.MODE_PARITY, RMSE_PARITY), (abi.MODE_FAST, RMSE_FAST)):
+    for mode in (abi.MODE_PARITY, abi.MODE_FAST):
         img, hits = tracer.render(max_depth=6, mode=mode)
-        assert (hits == ohits).all(axis=-1).mean() >= ID_BAR
-        st = image_stats(img, oimg)
-        assert st["rmse"] <= bar, (seed, builder, mode, st)
+        same = (hits == ohits).all(axis=-1).mean()
+        assert same >= ID_BAR, (seed, builder, mode, same)
+        check_image(img, oimg, mode, ("random scene", seed, builder))
 
 
 def test_textured_triangles_pool_variant_vs_oracle(tracer):
@@ -292,8 +288,9 @@ def test_headline_workload_properties(tracer):
     for key, (img, hits, rays) in res.items():
         if key == (False, abi.MODE_PARITY):
             continue
-        assert (hits == base_hits).all(axis=-1).mean() >= ID_BAR, key
-        assert image_stats(img, base_img)["rmse"] <= RMSE_FAST, key
+        same = (hits == base_hits).all(axis=-1).mean()
+        assert same >= ID_BAR, (key, same)
+        check_image(img, base_img, abi.MODE_FAST, ("headline workload vs PARITY on the reference tree", key))
         if rays is not None:
             assert abs(rays - base_rays) <= 1e-4 * base_rays, key
     r0 = 470
@@ -324,7 +321,8 @@ def test_diffuse_bounce_vs_oracle(tracer, default_model, bunny0_model):
         assert not np.array_equal(mirror, img)
         fast, fhits = tracer.render(max_depth=depth, mode=abi.MODE_FAST, diffuse=True)
         assert (fhits == ohits).all(axis=-1).mean() >= ID_BAR
-        assert image_stats(fast, oimg)["rmse"] <= 4 * RMSE_FAST
+        # a diffuse direction that moves by an ulp may send the path elsewhere: more pixels move than at mirror ties
+        check_image(fast, oimg, abi.MODE_FAST, ("diffuse bounces", W, H), frac_bar=1e-2)
         # stripes and sample ranges compose (the stream is keyed by pixel and sample of the full frame)
         stripe, _ = tracer.render(max_depth=depth, mode=abi.MODE_PARITY, rows=(32, 48), diffuse=True)
         assert np.array_equal(stripe, img[32:48])
@@ -423,7 +421,7 @@ def test_deep_chain_tree(tracer, n):
                 tracer.set_tuning(adapt=0, handoverList=[4])
             fast, fhits = tracer.render(max_depth=4, mode=abi.MODE_FAST)
             assert (fhits == ohits).all(axis=-1).mean() >= ID_BAR, early
-            assert image_stats(fast, oimg)["rmse"] <= RMSE_FAST, early
+            check_image(fast, oimg, abi.MODE_FAST, ("deep chain", n, early))
     finally:
         tracer.set_tuning(base)                             # thresholds back to their defaults for the tests that follow
 
@@ -451,16 +449,18 @@ def test_compacted_ray_lists_change_nothing(tracer, default_model, bunny0_model)
         tracer.set_tuning(base)
 
 
-def test_hand_over_kernels_agree(default_model, bunny0_model):
+def test_hand_over_kernels_agree(default_model, bunny0_model, pool_model):
     """FAST mode's continuation kernels (16 lanes per ray, and one wave per ray for deep trees) keep no visit order; the
     closest hit must come out all the same.  With a threshold of 4 trips nearly every ray goes through them: both must
-    agree with each other and with the default schedule (ties between coincident primitives aside, as in the FAST bars)."""
+    agree with each other and with the default schedule bit for bit (the default scene has coincident discs and the Pool
+    view along the water grid's diagonal has rays through shared edges: exact ties, decided by the primitive code)."""
     from raytracing_amd import tracer as T
     t = T.Tracer(0)
     base = t.get_tuning()
     try:
-        for m, (W, H) in ((default_model, (256, 256)), (bunny0_model, (640, 360))):
-            tr = m.camera(H)
+        gB, gP = load_golden("bvh_viewB_256"), load_golden("pool_viewA_160")
+        for m, (W, H), tr, variant in ((default_model, (256, 256), gB["trans"], abi.VARIANT_BVH), (bunny0_model, (640, 360), bunny0_model.camera(360), abi.VARIANT_BVH),
+                                       (pool_model, (160, 160), gP["trans"], abi.VARIANT_POOL)):
             res = {}
             for group in (None, 64, 16):
                 t.set_tuning(base)
@@ -469,14 +469,12 @@ def test_hand_over_kernels_agree(default_model, bunny0_model):
                 t.scene_upload(m.scene_view())
                 t.set_camera(tr, W, H)
                 t.set_decay_origin((0, 0, 0, 1))
-                res[group] = t.render(max_depth=4, mode=abi.MODE_FAST)
+                res[group] = t.render(max_depth=8 if variant == abi.VARIANT_POOL else 4, mode=abi.MODE_FAST, variant=variant)
+            # equal distances are decided by the primitive code and the triangle arithmetic is the same in the three kernels: the
+            # frame does not depend on which kernel finishes a ray
             for group in (64, 16):
-                same = (res[group][1] == res[None][1]).all(axis=-1).mean()
-                st = image_stats(res[group][0], res[None][0])
-                assert same >= 0.9995, (group, same)
-                assert st["rmse"] <= RMSE_FAST, (group, st)
-            assert (res[64][1] == res[16][1]).all(axis=-1).mean() >= ID_BAR
-            assert image_stats(res[64][0], res[16][0])["rmse"] <= RMSE_FAST
+                assert np.array_equal(res[group][1], res[None][1]), (group, int((res[group][1] != res[None][1]).any(axis=-1).sum()))
+                assert np.array_equal(res[group][0].view(np.uint32), res[None][0].view(np.uint32)), (group, image_stats(res[group][0], res[None][0]))
     finally:
         t.close()
 
@@ -545,7 +543,8 @@ def test_pool_decay_origin_and_water_update(tracer, pool_model):
     fast0, _ = tracer.render(max_depth=8, variant=abi.VARIANT_POOL, mode=abi.MODE_FAST)   # the FAST kernels see the update too
     tracer.update_triangles(0, moved)
     fast1, _ = tracer.render(max_depth=8, variant=abi.VARIANT_POOL, mode=abi.MODE_FAST)
-    assert image_stats(fast0, base)["rmse"] <= RMSE_FAST and image_stats(fast1, low)["rmse"] <= RMSE_FAST
+    check_image(fast0, base, abi.MODE_FAST, "pool water as uploaded, FAST vs PARITY")
+    check_image(fast1, low, abi.MODE_FAST, "pool water lowered, FAST vs PARITY")
     tracer.update_triangles(0, water)
 
 
@@ -637,7 +636,7 @@ def test_device_built_bvh_vs_llvmpipe_golden(tracer, default_model, bunny0_model
         # tools/diag_devbuild.py): those few pixels take the other disc's colour, all others meet the bar
         assert st["frac_gt_1e-3"] <= 5e-4, (name, mode, st)
     else:
-        assert st["rmse"] <= (RMSE_PARITY if mode == abi.MODE_PARITY else RMSE_FAST), (name, mode, st)
+        check_image(img, g["rgb"], mode, ("device-built tree", name))
 
 
 def test_device_built_bvh_counts_and_edge_cases(tracer, default_model):
@@ -677,7 +676,7 @@ def test_device_built_bvh_counts_and_edge_cases(tracer, default_model):
                 imgs.append(tracer.render(max_depth=4, mode=mode)[0])
         assert imgs[0][..., :3].max() > 0
         for im in imgs[1:]:
-            assert image_stats(im, imgs[0])["rmse"] <= RMSE_FAST
+            check_image(im, imgs[0], abi.MODE_FAST, ("one / two primitives", nprim))
 
 
 def test_rebuild_of_a_device_built_tree_follows_the_water(tracer, pool_model):
@@ -706,7 +705,7 @@ def test_rebuild_of_a_device_built_tree_follows_the_water(tracer, pool_model):
     for mode in (abi.MODE_PARITY, abi.MODE_FAST):
         img, hits = tracer.render(max_depth=8, variant=abi.VARIANT_POOL, mode=mode)
         assert (hits == ohits).all(axis=-1).mean() >= 0.9995, mode
-        assert image_stats(img, oimg)["rmse"] <= (RMSE_PARITY if mode == abi.MODE_PARITY else RMSE_FAST), mode
+        check_image(img, oimg, mode, "rebuilt tree over the moved water")
     # and again after more steps and a host-side triangle update
     tracer.water_step(100)
     tracer.update_triangles(0, ot[:nw])          # back to the state after 200 steps, through the host path
@@ -739,7 +738,7 @@ def test_sample_batches_change_nothing(tracer, default_model, name):
     """A frame of several samples is traced batch by batch (LrlTuning.batchSlots path slots per launch); the sum over the
     samples is taken in sample order whatever the batching, so PARITY images and primary ids are bit-identical for batches of
     1 (the per-sample pipeline), 2 + 2 + 1 and 5 samples, without and with glass (refraction stacks, polled iterations), and
-    with a sample range; FAST differs from itself only through the order-dependent hand-over thresholds (ties)."""
+    with a sample range; so are FAST's."""
     g = load_golden(name)
     W, H = g["width"], g["height"]
     tracer.scene_upload(default_model.scene_view())
@@ -764,13 +763,14 @@ def test_sample_batches_change_nothing(tracer, default_model, name):
         for b in (2, 5):
             assert np.array_equal(out[abi.MODE_PARITY, b][0].view(np.uint32), out[abi.MODE_PARITY, 1][0].view(np.uint32)), b
             assert np.array_equal(out[abi.MODE_PARITY, b][1], out[abi.MODE_PARITY, 1][1]), b
-            st = image_stats(out[abi.MODE_FAST, b][0], out[abi.MODE_FAST, 1][0])
-            assert st["rmse"] <= 1e-3 and (out[abi.MODE_FAST, b][1] == out[abi.MODE_FAST, 1][1]).all(axis=-1).mean() >= ID_BAR, (b, st)
+            # FAST frames do not depend on the schedule either (ties are decided by the primitive code)
+            assert np.array_equal(out[abi.MODE_FAST, b][0].view(np.uint32), out[abi.MODE_FAST, 1][0].view(np.uint32)), (b, image_stats(out[abi.MODE_FAST, b][0], out[abi.MODE_FAST, 1][0]))
+            assert np.array_equal(out[abi.MODE_FAST, b][1], out[abi.MODE_FAST, 1][1]), b
         st = image_stats(out[abi.MODE_FAST, 5][0], out[abi.MODE_PARITY, 5][0])
         if name == "bvh_viewB_128_spp4":      # diffuse bounces: a direction that moves by an ulp in FAST may land its path on a light's hot spot
             assert st["frac_gt_1e-3"] <= 2e-3, st
         else:
-            assert st["rmse"] <= RMSE_FAST, st
+            check_image(out[abi.MODE_FAST, 5][0], out[abi.MODE_PARITY, 5][0], abi.MODE_FAST, ("batched samples, glass", name))
     finally:
         tracer.set_tuning(base)
 
@@ -808,5 +808,7 @@ def test_c1_at_1024_vs_llvmpipe_golden(tracer, default_model, mode):
     sums = np.nan_to_num(img[..., :3].astype(np.float64), nan=0.0, posinf=0.0, neginf=0.0).reshape(H // T, T, W // T, T, 3).sum(axis=(1, 3))
     err = np.abs(sums - z["tile_sums"])
     # a tile sum is 256 pixels: the per-pixel RMSE bars (1e-4 PARITY, 5e-3 FAST) times sqrt(256) for independent errors
-    bar = (RMSE_PARITY if mode == abi.MODE_PARITY else RMSE_FAST) * 16
+    # a tile sum is 256 pixels: PARITY's per-pixel RMSE bar times sqrt(256) for independent errors; FAST: the gross-error guard (a tie pixel
+    # moves its tile's sum by up to 0.5)
+    bar = (RMSE_PARITY if mode == abi.MODE_PARITY else FAST_RMSE) * 16
     assert np.sqrt((err ** 2).mean()) <= bar, (mode, float(np.sqrt((err ** 2).mean())), float(err.max()), same)
