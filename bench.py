@@ -274,7 +274,7 @@ def main():
     if rehearse:
         local_rank = 0
         import faulthandler
-        faulthandler.dump_traceback_later(240, exit=True)     # a hang names its line
+        faulthandler.dump_traceback_later(90, exit=True)     # a hang names its line
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     if world > 1:
@@ -319,7 +319,29 @@ def run(a, torch, dist, sharding, rank, local_rank, world, dev, rehearse):
         outs = [torch.empty((H, W, 4), dtype=torch.float32, device=dev) for _ in range(2 if world > 1 else 1)]
     works = [None, None]
     counter = [0]
-    overlap = world > 1 and scaling == "weak" and not a.no_overlap
+    # The all-reduce of frame i overlaps the rendering of frame i + 1 (RCCL: stream-level waits only, the host never blocks).  Not in
+    # the one-GPU rehearsal: there the collectives run on host copies.  What round 1 recorded as a stall "inside lrl_render_async" was
+    # traced in round 2 (LrlTuning.debug = 2 prints a line around every HIP call of the render path; gpurun_out/r2_reh_weak*.err): every
+    # call of the render path returns, and a render with nothing of gloo's queued before it finishes on the device; what stops is the
+    # render stream's wait on the copy-back event of gloo's DEVICE-tensor all-reduce (its worker thread stages through pinned memory on
+    # pool streams of its own), with two processes on one GPU.  RCCL has no such thread and no staging.
+    overlap = world > 1 and scaling == "weak" and not a.no_overlap and not rehearse
+
+    def all_reduce_(t):
+        if rehearse:
+            h = t.cpu()
+            dist.all_reduce(h, op=dist.ReduceOp.SUM)
+            t.copy_(h)
+        else:
+            dist.all_reduce(t, op=dist.ReduceOp.SUM)
+
+    def all_gather_(full, mine):
+        if rehearse:
+            h = torch.empty(full.shape, dtype=full.dtype)
+            dist.all_gather_into_tensor(h, mine.cpu())
+            full.copy_(h)
+        else:
+            dist.all_gather_into_tensor(full, mine)
 
     def step():
         if world == 1:
@@ -331,15 +353,15 @@ def run(a, torch, dist, sharding, rank, local_rank, world, dev, rehearse):
             if scaling == "strong":
                 # one frame: my interleaved stripes, one all-gather, un-interleave
                 wl.render_into(part.data_ptr(), stream=raw)
-                dist.all_gather_into_tensor(gathered, part)
+                all_gather_(gathered, part)
                 frame[0] = gathered.index_select(0, idx_dev)
             elif not overlap:
                 wl.render_into(outs[0].data_ptr(), stream=raw)
-                dist.all_reduce(outs[0], op=dist.ReduceOp.SUM)
+                all_reduce_(outs[0])
             else:
                 # frame i renders (into the buffer whose all-reduce, of frame i - 2, was waited for in the last step) while the
-                # all-reduce of frame i - 1 runs; then that one is waited for (RCCL: a wait of the render stream, not of the host)
-                # and the all-reduce of frame i is queued behind its render: never more than one collective in flight
+                # all-reduce of frame i - 1 runs; then that one is waited for (a wait of the render stream, not of the host) and
+                # the all-reduce of frame i is queued behind its render: never more than one collective in flight
                 b = counter[0] & 1
                 wl.render_into(outs[b].data_ptr(), stream=raw)
                 if works[1 - b] is not None:

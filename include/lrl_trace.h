@@ -157,7 +157,8 @@ typedef struct LrlTuning {
     uint32_t traceRef;           /* 1: FAST arithmetic on the reference-order kernel (diagnostic)                           */
     uint32_t batchSlots;         /* spp > 1: samples are traced together up to this many path slots per launch;             */
                                  /*   0 = 2^23 (the chip fills at about 8 M rays per launch)                                */
-    uint32_t debug;              /* 1: per-frame diagnostics on stderr (adds host waits); 2: + a line around every HIP call */
+    uint32_t debug;              /* 1: per-frame diagnostics on stderr (adds host waits); 2: a line around every HIP call of the   */
+                                 /*   render path instead (no added waits); 3: both                                                */
 } LrlTuning;
 
 /* ---- life cycle ---- */

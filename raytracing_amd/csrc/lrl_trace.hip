@@ -1116,7 +1116,7 @@ static int renderWavefront(LrlContext* c, const LrlRenderParams* p, const KScene
             c->contSlotsInFlight = contSlots;
             CRUMB_TRY(c, "hipEventRecord(feedback)", hipEventRecord(c->evCont, stream));
         }
-        if (tn.debug && special) {
+        if ((tn.debug == 1 || tn.debug >= 3) && special) {      // (2: only the lines around the HIP calls, no added waits)
             std::vector<uint32_t> cc(iter);
             HIP_TRY(c, hipStreamSynchronize(stream));
             HIP_TRY(c, hipMemcpy(cc.data(), contCounts, iter * 4, hipMemcpyDeviceToHost));

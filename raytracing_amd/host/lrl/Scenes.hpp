@@ -212,6 +212,20 @@ inline void poolWaterSync(Model& m) {
         }
 }
 
+// The same heights as the water grid's points {z, v = 0, a = 0} (WaterData's initial state, Pool/Pool.cpp:97-112): what
+// lrl_water_init takes.
+inline std::vector<LrlWaterPoint> poolWaterPoints() {
+    const unsigned gx = 8 * 6, gy = 8 * 6;
+    const float z0 = 0.4f, dzMax = 0.15f;
+    const float cX = float((gx - 1) / 2), cY = float((gy - 1) / 2);
+    const double pi = 3.14159265358979323846;
+    std::vector<LrlWaterPoint> w(size_t(gx) * gy);
+    for (unsigned y = 0; y < gy; ++y)
+        for (unsigned x = 0; x < gx; ++x)
+            w[x + size_t(gx) * y] = LrlWaterPoint{z0 + dzMax * 0.5f * sinf(float(2 * pi * x / cX)) * sinf(float(2 * pi * y / cY)), 0.0f, 0.0f, 0.0f};
+    return w;
+}
+
 // Pool demo: 48 x 48 water grid as 2 * 47 * 47 tall proxy triangles (initModel, Pool/Pool.cpp:240-299; the heights come
 // from poolWaterSync after the BVH is built), then the 28 triangles of pool.stl with the per-triangle materials and uv of Pool/Pool.cpp:515-606,
 // one light, four texture layers (pool, brick, ceiling, floor) and the room cube map.
