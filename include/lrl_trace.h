@@ -147,16 +147,17 @@ typedef struct LrlTuning {
     uint32_t handoverListLen;    /* > 0: explicit thresholds per segment instead (the last one repeats)                     */
     uint32_t handoverList[LRL_TUNING_LIST_MAX];
     uint32_t adapt;              /* 1: thresholds ratchet up from the sampled work counters of earlier frames               */
-    uint32_t groupLanes;         /* lanes per handed-over ray: 8, 16 (default), 32, or 64 (a wave per ray)                  */
+    uint32_t groupLanes;         /* lanes per handed-over ray: 8, 16, 32, or 64 (a wave per ray); 0 = 16, or 64 for scenes   */
+                                 /*   beyond the caches (more than 1 GiB of node records)                                    */
     uint32_t contSlots;          /* hand-over records per launch; 0 = 262144 per 2^21 path slots of a launch                */
-    uint32_t groupCapX;          /* frontier entries per ray = 256 x this; 0 = by tree depth (1 or 2)                       */
+    uint32_t groupCapX;          /* frontier entries per ray = 256 x this (1, 2 or 4); 0 = by tree depth                    */
     uint32_t sparseFrom;         /* first segment traced with four-wave workgroups (5)                                      */
     int32_t  compactFrom;        /* first segment traced from compacted ray lists; 0 never; -1 = by regime                  */
     float    workLow;            /* frontier entries per handed-over ray below which a threshold doubles (12)               */
     uint32_t pollLag;            /* scenes with transmission: iterations the host polls behind the queue (1..3)             */
     uint32_t traceRef;           /* 1: FAST arithmetic on the reference-order kernel (diagnostic)                           */
     uint32_t batchSlots;         /* spp > 1: samples are traced together up to this many path slots per launch;             */
-                                 /*   0 = 2^23 (the chip fills at about 8 M rays per launch)                                */
+                                 /*   0 = 2^25, less where the ray state of a pass would pass 8 GiB                         */
     uint32_t debug;              /* 1: per-frame diagnostics on stderr (adds host waits); 2: a line around every HIP call of the   */
                                  /*   render path instead (no added waits); 3: both                                                */
 } LrlTuning;

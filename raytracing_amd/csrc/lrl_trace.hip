@@ -485,7 +485,7 @@ hipError_t noallocScratchFor(int device, void** out) {
 LrlTuning defaultTuning() {
     LrlTuning t{};
     t.handoverEarly = 48; t.handoverLate = 16; t.handoverListLen = 0;
-    t.adapt = 1; t.groupLanes = 16; t.contSlots = 0; t.groupCapX = 0; t.sparseFrom = 5; t.compactFrom = -1;
+    t.adapt = 1; t.groupLanes = 0; t.contSlots = 0; t.groupCapX = 0; t.sparseFrom = 5; t.compactFrom = -1;
     t.workLow = 12.0f; t.pollLag = 1; t.traceRef = 0; t.batchSlots = 0; t.debug = 0;
     return t;
 }
@@ -560,8 +560,8 @@ int lrl_get_tuning(const LrlContext* c, LrlTuning* out) {
 int lrl_set_tuning(LrlContext* c, const LrlTuning* t) {
     if (!c || !t) return LRL_ERR_INVALID_ARG;
     if (t->handoverListLen > LRL_TUNING_LIST_MAX) return fail(c, LRL_ERR_INVALID_ARG, "handoverListLen > LRL_TUNING_LIST_MAX");
-    if (t->groupLanes != 8 && t->groupLanes != 16 && t->groupLanes != 32 && t->groupLanes != 64) return fail(c, LRL_ERR_INVALID_ARG, "groupLanes must be 8, 16, 32 or 64");
-    if (t->groupCapX > 2 || t->compactFrom < -1 || !(t->workLow >= 0.0f)) return fail(c, LRL_ERR_INVALID_ARG, "groupCapX must be 0..2, compactFrom >= -1, workLow >= 0");
+    if (t->groupLanes != 0 && t->groupLanes != 8 && t->groupLanes != 16 && t->groupLanes != 32 && t->groupLanes != 64) return fail(c, LRL_ERR_INVALID_ARG, "groupLanes must be 0, 8, 16, 32 or 64");
+    if ((t->groupCapX > 2 && t->groupCapX != 4) || t->compactFrom < -1 || !(t->workLow >= 0.0f)) return fail(c, LRL_ERR_INVALID_ARG, "groupCapX must be 0, 1, 2 or 4, compactFrom >= -1, workLow >= 0");
     if (t->contSlots > (1u << 22)) return fail(c, LRL_ERR_LIMIT, "contSlots > 2^22");
     c->tuning = *t;
     c->handoverThr.clear();      // the adaptive thresholds start again from the new base values
@@ -914,9 +914,15 @@ static int renderWavefront(LrlContext* c, const LrlRenderParams* p, const KScene
     // the launches of a high-spp frame fill the chip (a 1080p sample is 2 M paths; the chip wants about 8 M rays per launch) and a frame
     // pays the tails of its launches once per batch instead of once per sample
     const uint32_t nSamples = f.sampleEnd - f.sampleBegin;
-    const uint64_t batchSlots = tn.batchSlots ? tn.batchSlots : (1u << 23);
+    // (measured, 1080p: C3 132.9 / 131.4 / 131.2 / 128.2 ms per 64-spp frame with batches of 4 / 8 / 16 / 32 samples, 148.8 with one; C5
+    // 67.6 / 63.1 / 60.3 ms per 16-spp frame with 4 / 8 / 16).  Default: 2^25 path slots per launch, as long as the arena stays within 8 GiB
+    const uint64_t batchSlots = tn.batchSlots ? tn.batchSlots : (1u << 25);
     uint32_t batch = uint32_t(std::min<uint64_t>(nSamples, std::max<uint64_t>(1, batchSlots / Ppix64)));
     while (batch > 1 && Ppix64 * batch * (1 + uint64_t(L)) >= (1ull << 31)) --batch;
+    if (!tn.batchSlots) {
+        const uint64_t perSlot = 16 * 6 + 4 + (1 + uint64_t(L)) * 36 + 64ull * (c->hasTransmission ? p->maxDepth : 0u);
+        while (batch > 1 && Ppix64 * batch * perSlot > (8ull << 30)) --batch;
+    }
     // Trace kernel per iteration.  PARITY and counting renders: wfTraceKernel (the reference's visit order).  FAST: the lean
     // one-lane-per-ray kernel over the four-wide tree, which hands rays that are still going after handoverTrips trips to the
     // lanes-per-ray kernel.
@@ -942,12 +948,18 @@ static int renderWavefront(LrlContext* c, const LrlRenderParams* p, const KScene
     // sample (160 ms a frame against 150 for any pinned state); a new scene starts from the defaults.  adapt = 0 pins them.
     // lanes per handed-over ray: groups of 16 when a group's share of the frontier holds the hand-over plus a depth-first
     // descent (lrl_lean.inc), else a wave per ray
-    uint32_t swarmGroup = tn.groupLanes;
+    // Beyond the caches (more than 1 GiB of node records) a round costs an HBM miss whatever it fetches, so a ray is better off with all
+    // 64 lanes and a 1024-entry frontier to itself (C5: 49.1 ms per frame with a wave per ray, 51.9 with 32 lanes, 60.0 with 16; C2, which
+    // sits in the caches: 1.43 / 1.38 / 1.32 ms)
+    const bool beyondCaches = size_t(c->recNum) * 64 > (size_t(1) << 30);
+    uint32_t swarmGroup = tn.groupLanes ? tn.groupLanes : beyondCaches ? 64u : 16u;
     if (swarmGroup != 8 && swarmGroup != 16 && swarmGroup != 32) swarmGroup = 64;
     // a ray's frontier: LRL_GROUP_CAP entries, twice that where the hand-over record + depth-first reserve (contStride) would
     // leave less than 2/5 of it for full rounds (groups of 16 lanes only)
-    const uint32_t groupCap = LRL_GROUP_CAP * ((swarmGroup == 16 && (tn.groupCapX ? tn.groupCapX >= 2 : 2 * contStride + 3 * swarmGroup > LRL_GROUP_CAP - 32)) ? 2u : 1u);      // C2 (stride 77): 256 is 1.3 % faster; 100 M device-built tree (95): 512 is 1.85x faster on C5
-    if (swarmGroup != 64 && 2 * contStride + 3 * swarmGroup > groupCap) swarmGroup = 64;
+    const uint32_t capX = tn.groupCapX ? tn.groupCapX : (swarmGroup == 16 && 2 * contStride + 3 * swarmGroup > LRL_GROUP_CAP - 32) ? 2u : 1u;      // C2 (stride 77): 256 is 1.3 % faster; 100 M device-built tree (95): 512 is 1.85x faster on C5
+    const bool instantiated = (swarmGroup == 16 && (capX == 1 || capX == 2 || capX == 4)) || (swarmGroup == 32 && (capX == 1 || capX == 2 || capX == 4)) || (swarmGroup == 8 && capX == 1);
+    const uint32_t groupCap = LRL_GROUP_CAP * (instantiated ? capX : 1u);
+    if (swarmGroup != 64 && (!instantiated || 2 * contStride + 3 * swarmGroup > groupCap)) swarmGroup = 64;
     const bool handoverFits = 2 * contStride + 192 <= LRL_SWARM_CAP;      // else (trees hundreds of levels deep) the lean kernel finishes every ray itself
     const uint32_t sparseFrom = tn.sparseFrom;      // (measured: C2 best with none of its 5, C1 with 8 of its 56, C3 with 4 of its 10)
     const bool adapt = tn.adapt != 0;
@@ -994,7 +1006,7 @@ static int renderWavefront(LrlContext* c, const LrlRenderParams* p, const KScene
     // 141.5 -> 132.6 ms); on C2 itself, the Pool and the default scene the extra kernel per iteration costs 1.5-10 %.
     // With more kinds of rays than LRL_LIST_KINDS (lights + 1) the masks are used throughout.
     const uint32_t compactFrom = (1 + L > LRL_LIST_KINDS) ? 0u : tn.compactFrom >= 0 ? uint32_t(tn.compactFrom)
-                                 : (f.diffuse || size_t(c->recNum) * 64 > (size_t(1) << 30)) ? 2u : 0u;
+                                 : (f.diffuse || beyondCaches) ? 2u : 0u;
 #ifdef LRL_DIAG
     const char* tlPath = std::getenv("LRL_TIMELINE");          // diagnostic builds only: timeline of ONE trace launch
     const char* tlIter = std::getenv("LRL_TIMELINE_ITER");
