@@ -116,15 +116,29 @@ def apply_tuning(tr, spec):
 
 
 def load_traffic(name, match):
-    """PMC passes are separate runs (tools/run_pmc.sh); their per-frame byte counts live in profiles/."""
+    """PMC passes are separate runs (tools/run_pmc_tag.sh); their per-frame counts live in profiles/.  Returns (HBM bytes of the trace
+    kernels per frame, VALU wave-instructions of the trace kernels per frame or None)."""
     path = os.path.join(REPO, "profiles", name)
     if not os.path.exists(path):
-        return None
+        return None, None
     tj = json.load(open(path))
     for k, v in match.items():
         if tj.get(k) != v:
-            return None
-    return tj.get("hbm_bytes_per_frame")
+            return None, None
+    valu = None
+    src = os.path.join(REPO, tj.get("source", ""))
+    if os.path.isfile(src):
+        valu = json.load(open(src)).get("trace_kernels_per_frame", {}).get("sq", {}).get("SQ_INSTS_VALU")
+    return tj.get("hbm_bytes_per_frame"), valu
+
+
+# tools/probes/hbm_gather.hip on this chip (profiles/r02_hbm_gather_probe.txt): what the memory system gives a traversal-shaped stream
+# of whole-record fetches, every one an L2 miss (one 128-B fabric request each)
+GATHER_PROBE = {"source": "profiles/r02_hbm_gather_probe.txt",
+                "requests_per_s_table_up_to_2GiB": 53e9, "requests_per_s_random_64B_records_16GiB": 19.6e9,
+                "requests_per_s_16GiB_four_lanes_per_record": 45e9,
+                "note": "beyond ~2 GiB a uniformly random gather is bound by address translation per lane, not by HBM; 53 G requests/s x 128 B = 6.8 TB/s"}
+SIMDS, CLOCK_GHZ = 1024, 2.4          # 256 CUs x 4 SIMDs; a wave64 VALU instruction occupies its SIMD for 4 cycles
 
 
 class Workload:
@@ -227,9 +241,9 @@ class Workload:
         # a FAST frame touches the four-wide nodes (half of `nodes`), the hot triangle records and the cold ones of the hits
         return d["nodes"] // 2 + d["tri_hot"] + d["tri_cold"] + d["other"]
 
-    def roofline(self, kernel_ms, launches, frame_ms, traffic):
+    def roofline(self, kernel_ms, launches, frame_ms, traffic, valu=None):
         resident = self.working_set() <= INFINITY_CACHE_BYTES
-        r = {"kernel": ("trace kernels of one frame (wfTraceLeanKernel + wfTraceGroupKernel)" if self.mode_name == "fast"
+        r = {"kernel": ("trace kernels of one frame (wfTraceLeanKernel + the hand-over kernel: wfTraceGroupKernel, or wfTraceSwarmKernel beyond the caches)" if self.mode_name == "fast"
                         else "trace kernels of one frame (wfTraceKernel)"),
              "kernel_ms": round(kernel_ms, 4), "launches_per_frame": launches, "frame_ms": round(frame_ms, 4),
              "working_set_bytes": self.working_set(), "traffic": traffic,
@@ -248,6 +262,15 @@ class Workload:
             r.update({"bound": "hbm", "level": "HBM: the working set is far beyond the 256 MiB Infinity Cache" if not resident else "Infinity Cache resident",
                       "achieved": round(ach, 2), "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBPS, 5),
                       "fetched_bytes_per_frame": int(self.fetch_bytes) if self.fetch_bytes else None})
+        if traffic:
+            # every L2 miss is one 128-B request (TCC_EA0_RDREQ_128B = TCC_EA0_RDREQ in the PMC passes)
+            r["hbm_line_requests_per_s"] = round(traffic / 128.0 / (kernel_ms * 1e-3), 0)
+            if not resident:
+                r["gather_probe"] = GATHER_PROBE
+        if valu:
+            # the other bound of a cache-resident traversal: VALU issue (PMC pass SQ_INSTS_VALU of the same kernels, a count that does
+            # not depend on the run, over this run's kernel time)
+            r["valu_issue"] = {"wave_instructions_per_frame": int(valu), "busy_frac": round(valu * 4.0 / (SIMDS * CLOCK_GHZ * 1e9 * kernel_ms * 1e-3), 4)}
         if not (0.0 < r["frac"] <= 1.0):
             r["frac_note"] = "frac outside (0, 1]: the caches serve part of these bytes; see hbm_frac and work"
         return r
@@ -416,10 +439,12 @@ def run(a, torch, dist, sharding, rank, local_rank, world, dev, rehearse):
     ms_per_step = elapsed / steps * 1e3
     value = rays_all * steps / elapsed / 1e6
     frame_ms = frame_ms_total / max(frames, 1)
-    traffic = None
+    traffic = valu = None
     if world == 1 and a.workload == "c2" and not a.tuning:
-        traffic = load_traffic("r02_traffic.json", {"workload_triangles": int(wl.view.num.triangleNum), "mode": a.mode, "builder": wl.builder,
+        traffic, valu = load_traffic("r02_traffic.json", {"workload_triangles": int(wl.view.num.triangleNum), "mode": a.mode, "builder": wl.builder,
                                                     "width": W, "height": H, "spp": wl.spp, "depth": wl.depth, "diffuse": wl.diffuse})
+    if world == 1 and a.workload == "c5" and not a.tuning and not (a.grid or a.spp or a.depth or a.width or a.builder or a.diffuse):
+        traffic, valu = load_traffic("r02_traffic_c5.json", {"workload_triangles": int(wl.view.num.triangleNum), "spp": wl.spp, "depth": wl.depth})
     if world > 1:
         par = (f"replicated scene, {wl.spp} sample indices per GPU, RCCL all-reduce of the image" + (" overlapping the next frame" if overlap else "")
                if scaling == "weak" else "replicated scene, interleaved 16-row stripes per GPU, RCCL all-gather of the frame")
@@ -433,8 +458,8 @@ def run(a, torch, dist, sharding, rank, local_rank, world, dev, rehearse):
                    "bvh_wide_depth": wl.info["wideDepth"], "arithmetic": a.mode, "parallelism": par,
                    "rays_per_frame": int(rays_all), "host_scene_build_s": round(wl.build_s, 2), "scene_upload_s": round(wl.upload_s, 2),
                    "device_scene_bytes": wl.tr.scene_device_bytes(),
-                   "schedule": {k: rinfo[k] for k in ("passes", "batch", "iterations", "compactFrom", "groupLanes", "frontierEntries", "contSlots")}},
-        "roofline": wl.roofline(kernel_ms, launches, frame_ms, traffic),
+                   "schedule": {k: rinfo[k] for k in ("passes", "batch", "iterations", "compactFrom", "groupLanes", "frontierEntries", "contSlots", "coopFetch")}},
+        "roofline": wl.roofline(kernel_ms, launches, frame_ms, traffic, valu),
     }
     if not a.no_cpu_baseline and world == 1:
         line["cpu_baseline"] = cpu_baseline(a, wl)
@@ -465,8 +490,8 @@ def roofline_c5(a, local_rank, torch, dev):
     elapsed = time.perf_counter() - t0
     frame_ms_total, frames = wl.tr.timing_end()
     kernel_ms, launches = wl.trace_kernel_ms(out.data_ptr(), 1)
-    traffic = load_traffic("r02_traffic_c5.json", {"workload_triangles": int(wl.view.num.triangleNum), "spp": wl.spp, "depth": wl.depth})
-    r = wl.roofline(kernel_ms, launches, frame_ms_total / max(frames, 1), traffic)
+    traffic, valu = load_traffic("r02_traffic_c5.json", {"workload_triangles": int(wl.view.num.triangleNum), "spp": wl.spp, "depth": wl.depth})
+    r = wl.roofline(kernel_ms, launches, frame_ms_total / max(frames, 1), traffic, valu)
     r.update({"workload": wl.describe(), "bvh_builder": wl.builder, "bvh_depth": wl.info["bvhDepth"], "bvh_wide_depth": wl.info["wideDepth"],
               "Mrays_per_s": round(wl.rays * steps / elapsed / 1e6, 2), "ms_per_frame": round(elapsed / steps * 1e3, 3), "steps": steps,
               "rays_per_frame": int(wl.rays), "host_scene_build_s": round(wl.build_s, 2), "scene_upload_and_build_s": round(wl.upload_s, 2),

@@ -158,6 +158,9 @@ typedef struct LrlTuning {
     uint32_t traceRef;           /* 1: FAST arithmetic on the reference-order kernel (diagnostic)                           */
     uint32_t batchSlots;         /* spp > 1: samples are traced together up to this many path slots per launch;             */
                                  /*   0 = 2^25, less where the ray state of a pass would pass 8 GiB                         */
+    uint32_t coopFetch;          /* 1: the trace kernels fetch a 64-B record with four lanes (same records, same frame bit for bit).  A uniformly */
+                                 /*   random gather out of more than ~2 GiB is bound by address translations per lane and gains 2.3x that way    */
+                                 /*   (tools/probes/hbm_gather.hip); the rays of the measured scenes are more coherent and lose ~12 %.  0: off   */
     uint32_t debug;              /* 1: per-frame diagnostics on stderr (adds host waits); 2: a line around every HIP call of the   */
                                  /*   render path instead (no added waits); 3: both                                                */
 } LrlTuning;
@@ -258,6 +261,7 @@ typedef struct LrlRenderInfo {       /* of the last wavefront-pipeline render */
     uint32_t groupLanes;     /* lanes per handed-over ray actually used (64: a wave per ray)                               */
     uint32_t frontierEntries;/* frontier entries per handed-over ray (256 or 512)                                          */
     uint32_t contSlots, contStride;
+    uint32_t coopFetch;      /* 1: the trace kernels fetched records with four lanes to a record                            */
     uint32_t handoverTrips[8]; /* thresholds of the first eight segments as the last pass used them (0: no hand-over)      */
 } LrlRenderInfo;
 int lrl_last_render_info(const LrlContext* ctx, LrlRenderInfo* out);

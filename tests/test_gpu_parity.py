@@ -449,6 +449,35 @@ def test_compacted_ray_lists_change_nothing(tracer, default_model, bunny0_model)
         tracer.set_tuning(base)
 
 
+def test_cooperative_record_fetches_change_nothing(tracer, default_model, bunny0_model, pool_model):
+    """LrlTuning.coopFetch: the FAST trace kernels fetch a 64-B record with four lanes (lanes l, l+16, l+32, l+48 read its four parts,
+    a transpose of v_permlane swaps brings them home; a remedy for gathers bound by address translation, off by default).  The record a
+    lane ends up with is the same 64 bytes, so the frame must be the same bit for bit: forced on here for the lean kernel over
+    mask words and over compacted lists, and for the wave-per-ray hand-over kernel (threshold 4: nearly every ray goes through it),
+    on scenes with every primitive class, exact ties and partly filled waves."""
+    base = tracer.get_tuning()
+    try:
+        gP = load_golden("pool_viewA_160")
+        for m, (W, H), tr, variant in ((default_model, (200, 168), default_model.camera(168), abi.VARIANT_BVH),
+                                       (bunny0_model, (320, 184), bunny0_model.camera(184), abi.VARIANT_BVH),
+                                       (pool_model, (160, 160), gP["trans"], abi.VARIANT_POOL)):
+            tracer.scene_upload(m.scene_view())
+            tracer.set_camera(tr, W, H)
+            tracer.set_decay_origin((0, 0, 0, 1))
+            for extra in ({}, {"compactFrom": 1}, {"adapt": 0, "handoverList": [4], "groupLanes": 64}):
+                for diffuse in (False, True):
+                    frames = {}
+                    for coop in (0, 1):
+                        tracer.set_tuning(base)
+                        tracer.set_tuning(coopFetch=coop, **extra)
+                        frames[coop] = tracer.render(max_depth=5, mode=abi.MODE_FAST, variant=variant, diffuse=diffuse)
+                        assert tracer.last_render_info()["coopFetch"] == coop
+                    assert np.array_equal(frames[1][1], frames[0][1]), (extra, diffuse, int((frames[1][1] != frames[0][1]).any(axis=-1).sum()))
+                    assert np.array_equal(frames[1][0].view(np.uint32), frames[0][0].view(np.uint32)), (extra, diffuse, image_stats(frames[1][0], frames[0][0]))
+    finally:
+        tracer.set_tuning(base)
+
+
 def test_hand_over_kernels_agree(default_model, bunny0_model, pool_model):
     """FAST mode's continuation kernels (16 lanes per ray, and one wave per ray for deep trees) keep no visit order; the
     closest hit must come out all the same.  With a threshold of 4 trips nearly every ray goes through them: both must
