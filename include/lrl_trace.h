@@ -161,6 +161,8 @@ typedef struct LrlTuning {
     uint32_t coopFetch;          /* 1: the trace kernels fetch a 64-B record with four lanes (same records, same frame bit for bit).  A uniformly */
                                  /*   random gather out of more than ~2 GiB is bound by address translations per lane and gains 2.3x that way    */
                                  /*   (tools/probes/hbm_gather.hip); the rays of the measured scenes are more coherent and lose ~12 %.  0: off   */
+    uint32_t streamWords;        /* > 1: the lean trace kernel runs as waves that own this many 64-ray words of a launch and hand the next rays  */
+    uint32_t refillMin;          /*   of their words to idle lanes whenever at least refillMin (16) lanes are idle; 0 / 1: one word per wave        */
     uint32_t debug;              /* 1: per-frame diagnostics on stderr (adds host waits); 2: a line around every HIP call of the   */
                                  /*   render path instead (no added waits); 3: both                                                */
 } LrlTuning;
@@ -262,6 +264,7 @@ typedef struct LrlRenderInfo {       /* of the last wavefront-pipeline render */
     uint32_t frontierEntries;/* frontier entries per handed-over ray (256 or 512)                                          */
     uint32_t contSlots, contStride;
     uint32_t coopFetch;      /* 1: the trace kernels fetched records with four lanes to a record                            */
+    uint32_t streamWords;    /* words per wave of the lean kernel with lane refill (0: one-word waves)                      */
     uint32_t handoverTrips[8]; /* thresholds of the first eight segments as the last pass used them (0: no hand-over)      */
 } LrlRenderInfo;
 int lrl_last_render_info(const LrlContext* ctx, LrlRenderInfo* out);

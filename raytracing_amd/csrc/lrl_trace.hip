@@ -485,7 +485,7 @@ hipError_t noallocScratchFor(int device, void** out) {
 LrlTuning defaultTuning() {
     LrlTuning t{};
     t.handoverEarly = 48; t.handoverLate = 16; t.handoverListLen = 0;
-    t.adapt = 1; t.groupLanes = 0; t.contSlots = 0; t.groupCapX = 0; t.sparseFrom = 5; t.compactFrom = -1; t.coopFetch = 0;
+    t.adapt = 1; t.groupLanes = 0; t.contSlots = 0; t.groupCapX = 0; t.sparseFrom = 5; t.compactFrom = -1; t.coopFetch = 0; t.streamWords = 0; t.refillMin = 16;
     t.workLow = 12.0f; t.pollLag = 1; t.traceRef = 0; t.batchSlots = 0; t.debug = 0;
     return t;
 }
@@ -564,6 +564,7 @@ int lrl_set_tuning(LrlContext* c, const LrlTuning* t) {
     if ((t->groupCapX > 2 && t->groupCapX != 4) || t->compactFrom < -1 || !(t->workLow >= 0.0f)) return fail(c, LRL_ERR_INVALID_ARG, "groupCapX must be 0, 1, 2 or 4, compactFrom >= -1, workLow >= 0");
     if (t->contSlots > (1u << 22)) return fail(c, LRL_ERR_LIMIT, "contSlots > 2^22");
     if (t->coopFetch > 1) return fail(c, LRL_ERR_INVALID_ARG, "coopFetch must be 0 or 1");
+    if (t->streamWords > 4096 || t->refillMin > 64) return fail(c, LRL_ERR_INVALID_ARG, "streamWords <= 4096, refillMin <= 64");
     c->tuning = *t;
     c->handoverThr.clear();      // the adaptive thresholds start again from the new base values
     c->feedbackTick = 0;
@@ -958,6 +959,8 @@ static int renderWavefront(LrlContext* c, const LrlRenderParams* p, const KScene
     // per lane bound it: tools/probes/hbm_gather.hip), but the rays of C5 are not that incoherent: 54.2 against 48.5 ms per frame (every kernel
     // of the frame ~15 % slower: idle lanes fetch too, 8 shuffles + 16 swaps a trip).  Off unless asked for.
     const bool coop = tn.coopFetch == 1;
+    // lane refill (wfTraceLeanStreamKernel): waves that own streamWords words of a launch
+    const uint32_t streamWords = tn.streamWords, refillMin = tn.refillMin ? std::min(64u, tn.refillMin) : 16u;
     if (swarmGroup != 8 && swarmGroup != 16 && swarmGroup != 32) swarmGroup = 64;
     // a ray's frontier: LRL_GROUP_CAP entries, twice that where the hand-over record + depth-first reserve (contStride) would
     // leave less than 2/5 of it for full rounds (groups of 16 lanes only)
@@ -1100,7 +1103,7 @@ static int renderWavefront(LrlContext* c, const LrlRenderParams* p, const KScene
                 wf.contWork = contWorkAll + size_t(fi) * LRL_WORK_COUNTERS * 32;
                 const bool compact = compactFrom != 0 && iter >= compactFrom && iter < LRL_WF_MAX_ITERATIONS;
                 wf.listCount = listCounts + size_t(iter < LRL_WF_MAX_ITERATIONS ? iter : 0) * LRL_LIST_KINDS;
-                CRUMB_TRY(c, "trace (lean)", lrl_fast::wfLaunchTraceLean(k, wf, iter >= sparseFrom, compact, coop, stream));
+                CRUMB_TRY(c, "trace (lean)", lrl_fast::wfLaunchTraceLean(k, wf, iter >= sparseFrom, compact, coop, streamWords, refillMin, stream));
                 if (wf.handoverTrips) CRUMB_TRY(c, "trace (hand-over)", lrl_fast::wfLaunchTraceSwarm(k, wf, std::min(contSlots, c->swarmGrid[fi]), swarmGroup, coop, stream));
             }
             else CRUMB_TRY(c, "trace", fast ? lrl_fast::wfLaunchTrace(k, wf, stream) : lrl_parity::wfLaunchTrace(k, wf, stream));
@@ -1149,7 +1152,7 @@ static int renderWavefront(LrlContext* c, const LrlRenderParams* p, const KScene
     ri = LrlRenderInfo{};
     ri.iterations = iterations; ri.passes = passIndex; ri.batch = batch;
     if (special) {
-        ri.compactFrom = compactFrom; ri.coopFetch = coop ? 1u : 0u; ri.groupLanes = swarmGroup; ri.frontierEntries = swarmGroup == 64 ? LRL_SWARM_CAP : groupCap;
+        ri.compactFrom = compactFrom; ri.coopFetch = coop ? 1u : 0u; ri.streamWords = coop ? 0u : streamWords; ri.groupLanes = swarmGroup; ri.frontierEntries = swarmGroup == 64 ? LRL_SWARM_CAP : groupCap;
         ri.contSlots = contSlots; ri.contStride = contStride;
         for (uint32_t i = 0; i < 8; ++i) ri.handoverTrips[i] = handoverFits ? c->handoverThr[i] : 0u;
     }

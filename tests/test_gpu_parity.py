@@ -478,6 +478,37 @@ def test_cooperative_record_fetches_change_nothing(tracer, default_model, bunny0
         tracer.set_tuning(base)
 
 
+def test_lane_refill_changes_nothing(tracer, default_model, bunny0_model, pool_model):
+    """LrlTuning.streamWords: the lean trace kernel as waves that own several 64-ray words and hand the next rays to idle lanes
+    (wfTraceLeanStreamKernel).  A ray's result does not depend on the lane that carries it or on when it starts: frames are the same
+    bit for bit as with one-word waves, over mask words and compacted lists, with the hand-over counting each ray's own trips, with
+    samples in batches (words of several samples in one wave), every primitive class, exact ties, and refills of one lane at a time."""
+    base = tracer.get_tuning()
+    try:
+        gP = load_golden("pool_viewA_160")
+        jit = host.jitter_table(4)
+        for m, (W, H), tr, variant in ((default_model, (200, 168), default_model.camera(168), abi.VARIANT_BVH),
+                                       (bunny0_model, (320, 184), bunny0_model.camera(184), abi.VARIANT_BVH),
+                                       (pool_model, (160, 160), gP["trans"], abi.VARIANT_POOL)):
+            tracer.scene_upload(m.scene_view())
+            tracer.set_camera(tr, W, H)
+            tracer.set_decay_origin((0, 0, 0, 1))
+            for extra in ({}, {"compactFrom": 1}, {"adapt": 0, "handoverList": [6]}):
+                for diffuse in (False, True):
+                    tracer.set_tuning(base)
+                    tracer.set_tuning(**extra)
+                    ref = tracer.render(max_depth=5, mode=abi.MODE_FAST, variant=variant, diffuse=diffuse, jitter=jit)
+                    for words, refill in ((2, 16), (8, 16), (64, 1), (5, 40)):
+                        tracer.set_tuning(base)
+                        tracer.set_tuning(streamWords=words, refillMin=refill, **extra)
+                        got = tracer.render(max_depth=5, mode=abi.MODE_FAST, variant=variant, diffuse=diffuse, jitter=jit)
+                        assert tracer.last_render_info()["streamWords"] == words
+                        assert np.array_equal(got[1], ref[1]), (extra, diffuse, words, refill, int((got[1] != ref[1]).any(axis=-1).sum()))
+                        assert np.array_equal(got[0].view(np.uint32), ref[0].view(np.uint32)), (extra, diffuse, words, refill, image_stats(got[0], ref[0]))
+    finally:
+        tracer.set_tuning(base)
+
+
 def test_hand_over_kernels_agree(default_model, bunny0_model, pool_model):
     """FAST mode's continuation kernels (16 lanes per ray, and one wave per ray for deep trees) keep no visit order; the
     closest hit must come out all the same.  With a threshold of 4 trips nearly every ray goes through them: both must
