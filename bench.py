@@ -11,16 +11,20 @@ the CPU oracle's counts, tests/).
                   [--builder reference|median|device] [--tuning key=value,...]
 
 Roofline (two records in the one JSON line):
-  roofline     the timed workload.  C1-C4 touch a working set that sits in the 256 MiB Infinity Cache (C2: 160 MB), so no HBM number
-               bounds them; what does is the vector L1's gather rate (one 64-B record per lane and trip).  `achieved` = bytes the
-               timed trace kernels fetch (64 B x their record fetches, counted by a counting instantiation of those same kernels) /
-               their device time (HIP events around every trace launch, on the stream they run on); `peak` = the L1 gather rate of
-               that access shape measured on this chip (tools/probes/l1_gather.hip: 171 CU-cycles per wave of 64 own-record
-               loads = 14.7 TB/s; the guide has no L1 figure); `traffic` = bytes beyond L2 from the PMC passes (profiles/);
-               `hbm_frac` = traffic / kernel time / 8 TB/s; `work` = SURVEY 8d's algorithmic bytes (reference-order visit counts).
+  roofline     the timed workload.  C1-C4 touch a working set that sits in the 256 MiB Infinity Cache (C2: 199 MB), so no HBM number
+               bounds them.  What does, by the counters (profiles/r02_c2_pmc.json), is VALU issue: `bound` = "valu", `achieved` = wave64
+               VALU instructions of the trace kernels per second (PMC pass SQ_INSTS_VALU of the same kernels on the same workload, a
+               count that does not depend on the run, over this run's trace-kernel time: HIP events around every trace launch on the
+               stream they run on), `peak` = 1024 SIMDs x 2.4 GHz / 4 cycles per instruction.  Second: `l1_gather` = bytes the timed
+               kernels fetch (64 B x their record fetches, counted by a counting instantiation of those same kernels) against the
+               vector L1's gather rate for that access shape measured on this chip (tools/probes/l1_gather.hip: 14.7 TB/s; the guide
+               has no L1 figure).  `traffic` = bytes beyond L2 from the PMC passes (FETCH_SIZE x 2 + WRITE_SIZE, profiles/), `hbm_frac`
+               = traffic / kernel time / 8 TB/s; `work` = SURVEY 8d's algorithmic bytes (reference-order visit counts).  Workloads
+               without a PMC record of their own (other scenes, --tuning) report `bound` = "l1" with the gather figure.
   roofline_c5  SURVEY 8d's C5, the configuration the memory roofline is judged on (100.5 M triangles, device-built tree, diffuse
                bounces, 16 spp; 22 GB of scene, far beyond the caches): `achieved` = algorithmic bytes / trace-kernel time against
-               the 8 TB/s HBM peak, with PMC traffic and hbm_frac.  N = 1 default runs only (--no-c5 skips it).
+               the 8 TB/s HBM peak, with PMC traffic, hbm_frac, the HBM line-request rate beside what tools/probes/hbm_gather.hip
+               measured this chip to give such a stream, and valu_issue.  N = 1 default runs only (--no-c5 skips it).
 
 N > 1 (one rank per GPU; `python bench.py --gpus N` starts the ranks itself through torch.distributed.run when it is not already
 under one): the scene is replicated.
@@ -252,11 +256,27 @@ class Workload:
                       "algorithmic_GBps": round(self.alg_bytes / (kernel_ms * 1e-3) / 1e9, 2),
                       "counts": {"node_visits": int(self.cn.nodeVisits), "tri_tests": int(self.cn.triTests), "sphere_tests": int(self.cn.sphereTests),
                                  "other_tests": int(self.cn.otherTests), "rays": int(self.rays)}}}
+        if valu:
+            # VALU issue: PMC pass SQ_INSTS_VALU of the same kernels on the same workload (a count that does not depend on the run: profiles/)
+            # over this run's kernel time; a wave64 instruction occupies its 16-lane SIMD for four cycles
+            peak = SIMDS * CLOCK_GHZ / 4.0                     # G wave-instructions per second
+            r["valu_issue"] = {"wave_instructions_per_frame": int(valu), "achieved": round(valu / (kernel_ms * 1e-3) / 1e9, 2), "peak": round(peak, 1),
+                               "unit": "G wave-instructions/s", "busy_frac": round(valu / (kernel_ms * 1e-3) / 1e9 / peak, 4)}
         if resident and self.fetch_bytes:
             ach = self.fetch_bytes / (kernel_ms * 1e-3) / 1e9
-            r.update({"bound": "l1", "level": "vector L1 gather rate; the working set is resident in the Infinity Cache / L2, HBM is nearly idle",
-                      "achieved": round(ach, 2), "peak": round(L1_GATHER_PEAK_GBPS, 1), "unit": "GB/s", "frac": round(ach / L1_GATHER_PEAK_GBPS, 5),
-                      "fetched_bytes_per_frame": int(self.fetch_bytes)})
+            l1 = {"achieved": round(ach, 2), "peak": round(L1_GATHER_PEAK_GBPS, 1), "unit": "GB/s", "frac": round(ach / L1_GATHER_PEAK_GBPS, 5),
+                  "fetched_bytes_per_frame": int(self.fetch_bytes),
+                  "note": "64 B x record fetches of the timed kernels (their counting instantiation) against the vector L1's rate for 64 lanes that each read their "
+                          "OWN record (tools/probes/l1_gather.hip); lanes that share a record cost less, so scenes of a few thousand triangles can pass 1"}
+            if valu:
+                # what binds a cache-resident frame: the counters say VALU issue (profiles/r02_c2_pmc.json), with the L1 gather rate second
+                r.update({"bound": "valu", "level": "VALU issue of the trace kernels; the working set is resident in the Infinity Cache / L2, HBM is nearly idle",
+                          "achieved": r["valu_issue"]["achieved"], "peak": r["valu_issue"]["peak"], "unit": r["valu_issue"]["unit"],
+                          "frac": r["valu_issue"]["busy_frac"], "l1_gather": l1})
+            else:
+                r.update({"bound": "l1", "level": "vector L1 gather rate; the working set is resident in the Infinity Cache / L2, HBM is nearly idle"})
+                r.update({k: l1[k] for k in ("achieved", "peak", "unit", "frac", "fetched_bytes_per_frame")})
+                r["l1_note"] = l1["note"]
         else:
             ach = self.alg_bytes / (kernel_ms * 1e-3) / 1e9
             r.update({"bound": "hbm", "level": "HBM: the working set is far beyond the 256 MiB Infinity Cache" if not resident else "Infinity Cache resident",
@@ -267,10 +287,6 @@ class Workload:
             r["hbm_line_requests_per_s"] = round(traffic / 128.0 / (kernel_ms * 1e-3), 0)
             if not resident:
                 r["gather_probe"] = GATHER_PROBE
-        if valu:
-            # the other bound of a cache-resident traversal: VALU issue (PMC pass SQ_INSTS_VALU of the same kernels, a count that does
-            # not depend on the run, over this run's kernel time)
-            r["valu_issue"] = {"wave_instructions_per_frame": int(valu), "busy_frac": round(valu * 4.0 / (SIMDS * CLOCK_GHZ * 1e9 * kernel_ms * 1e-3), 4)}
         if not (0.0 < r["frac"] <= 1.0):
             r["frac_note"] = "frac outside (0, 1]: the caches serve part of these bytes; see hbm_frac and work"
         return r

@@ -8,6 +8,7 @@
  *   model.dataInit()                BVH/BVH.cpp:722        lrl_scene_upload
  *   TrianglePre / CirclePre         BVH/BVH.cpp:159-168    (inside lrl_scene_upload / _update_triangles)
  *   triangles re-upload each frame  Pool/Pool.cpp:654-655  lrl_scene_update_triangles
+ *   Movement::run + dataInit        BVH/BVH.cpp:187-205    lrl_scene_update_primitives (+ lrl_scene_update_bvh)
  *   frameSizeUniform / transUniform BVH/BVH.cpp:718-720,   lrl_set_camera
  *     .dataInit()/.refreshData()        730,736
  *   decayOriginStorage.dataInit()   BVH/BVH.cpp:721        lrl_set_decay_origin
@@ -188,6 +189,20 @@ int lrl_scene_update_triangles(LrlContext* ctx, uint32_t first, uint32_t count, 
  * race; calls on one context follow each other (the call returns when its kernels are done). */
 #define LRL_NOALLOC_MAX_TRIANGLES 65536u
 int lrl_scene_update_triangles_noalloc(LrlContext* ctx, uint32_t first, uint32_t count, const LrlTriangle* tris);
+/* Movement::run (BVH/BVH.cpp:187-205: spheres and a point light move, then model.dataInit() uploads everything again, :203; disabled at
+ * :726 in the shipped demo): replaces records [first, first + count) of ONE primitive class in place, in the reference's record layout
+ * (CirclePre runs on new circles).  kind = the BVH geometry code of the class, or LRL_PRIM_LIGHT.  Lights need nothing else.  Geometry is
+ * found through the tree, so when a primitive may have left its leaf box follow with
+ *   lrl_scene_update_bvh(ctx, model.bvh, n)  caller's tree: the tree the host builder made for the new positions, over the SAME primitive
+ *                                            counts (what model.dataInit() uploads to SSBO 9); validated like lrl_scene_upload's
+ *   lrl_scene_rebuild_bvh(ctx)               library's tree: this call has already refreshed the leaf boxes of the new records */
+#define LRL_PRIM_SPHERE 3u
+#define LRL_PRIM_CIRCLE 4u
+#define LRL_PRIM_CYLINDER 5u
+#define LRL_PRIM_CONE 6u
+#define LRL_PRIM_LIGHT 0x100u
+int lrl_scene_update_primitives(LrlContext* ctx, uint32_t kind, uint32_t first, uint32_t count, const void* records);
+int lrl_scene_update_bvh(LrlContext* ctx, const LrlBVHNode* bvh, uint32_t bvhNodeNum);
 /* read back device results of the pre-compute kernels (tests / debugging) */
 int lrl_scene_read_triangles_gpu(LrlContext* ctx, uint32_t first, uint32_t count, LrlTriangleGPU* out);
 int lrl_scene_read_circles(LrlContext* ctx, uint32_t first, uint32_t count, LrlCircle* out);

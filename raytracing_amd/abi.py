@@ -101,6 +101,9 @@ class OracleParams(C.Structure):
                 ("decayOrigin", C.c_float * 4), ("diffuse", C.c_uint32)]
 
 
+PRIM_SPHERE, PRIM_CIRCLE, PRIM_CYLINDER, PRIM_CONE, PRIM_LIGHT = 3, 4, 5, 6, 0x100      # LRL_PRIM_* (include/lrl_trace.h)
+
+
 def scene_view_arrays(view):
     """Copy the arrays a SceneView points at into numpy records (for fixtures and tests)."""
     def arr(ptr, n, dt):

@@ -353,6 +353,32 @@ void boxFromDisc(const float c[3], const float n[3], float R, float mn[3], float
     }
 }
 
+// leaf box of record i of a primitive class that is no triangle (kind = the BVH geometry code 3..6)
+static void otherBox(uint32_t kind, const void* records, uint32_t i, float mn[3], float mx[3]) {
+    if (kind == 3) {
+        const LrlSphere& q = static_cast<const LrlSphere*>(records)[i];
+        const float d = float(1.05 * double(std::sqrt(q.sphere[3])));
+        for (int k = 0; k < 3; ++k) { mn[k] = q.sphere[k] - d; mx[k] = q.sphere[k] + d; }
+    } else if (kind == 4) {
+        const LrlCircle& q = static_cast<const LrlCircle*>(records)[i];
+        boxFromDisc(q.sphere, q.plane, std::sqrt(q.sphere[3]), mn, mx);
+    } else if (kind == 5) {
+        const LrlCylinder& q = static_cast<const LrlCylinder*>(records)[i];
+        boxFromDisc(q.c, q.n, std::sqrt(q.r2), mn, mx);
+        for (int k = 0; k < 3; ++k) {
+            const float sh = q.n[k] * q.l;
+            mn[k] = std::min(mn[k], mn[k] + sh);
+            mx[k] = std::max(mx[k], mx[k] + sh);
+        }
+    } else {
+        const LrlCone& q = static_cast<const LrlCone*>(records)[i];
+        const float h = std::sqrt(q.c2 * q.l2), R = std::sqrt((1 - q.c2) * q.l2);
+        const float base[3] = {q.c[0] + q.n[0] * h, q.c[1] + q.n[1] * h, q.c[2] + q.n[2] * h};
+        boxFromDisc(base, q.n, R, mn, mx);
+        for (int k = 0; k < 3; ++k) { mn[k] = std::min(mn[k], q.c[k]); mx[k] = std::max(mx[k], q.c[k]); }
+    }
+}
+
 int runDeviceBuild(LrlContext* c, uint32_t prims, uint32_t& recCount, uint32_t& depth);
 
 int buildOnDevice(LrlContext* c, const LrlSceneView* s, uint32_t prims, uint32_t& recCount, uint32_t& depth) {
@@ -367,38 +393,14 @@ int buildOnDevice(LrlContext* c, const LrlSceneView* s, uint32_t prims, uint32_t
         omax[o] = make_float4(mx[0], mx[1], mx[2], 0.0f);
         ++o;
     };
-    for (uint32_t i = 0; i < g.sphereNum; ++i) {
-        const LrlSphere& q = s->spheres[i];
-        const float d = float(1.05 * double(std::sqrt(q.sphere[3])));
-        const float mn[3] = {q.sphere[0] - d, q.sphere[1] - d, q.sphere[2] - d}, mx[3] = {q.sphere[0] + d, q.sphere[1] + d, q.sphere[2] + d};
-        put(mn, mx, 3, i);
-    }
-    for (uint32_t i = 0; i < g.circleNum; ++i) {
-        const LrlCircle& q = s->circles[i];
-        float mn[3], mx[3];
-        boxFromDisc(q.sphere, q.plane, std::sqrt(q.sphere[3]), mn, mx);
-        put(mn, mx, 4, i);
-    }
-    for (uint32_t i = 0; i < g.cylinderNum; ++i) {
-        const LrlCylinder& q = s->cylinders[i];
-        float mn[3], mx[3];
-        boxFromDisc(q.c, q.n, std::sqrt(q.r2), mn, mx);
-        for (int k = 0; k < 3; ++k) {
-            const float sh = q.n[k] * q.l;
-            mn[k] = std::min(mn[k], mn[k] + sh);
-            mx[k] = std::max(mx[k], mx[k] + sh);
+    const void* const arrays[7] = {nullptr, nullptr, nullptr, s->spheres, s->circles, s->cylinders, s->cones};
+    const uint32_t counts[7] = {0, 0, 0, g.sphereNum, g.circleNum, g.cylinderNum, g.coneNum};
+    for (uint32_t kind = 3; kind <= 6; ++kind)
+        for (uint32_t i = 0; i < counts[kind]; ++i) {
+            float mn[3], mx[3];
+            otherBox(kind, arrays[kind], i, mn, mx);
+            put(mn, mx, kind, i);
         }
-        put(mn, mx, 5, i);
-    }
-    for (uint32_t i = 0; i < g.coneNum; ++i) {
-        const LrlCone& q = s->cones[i];
-        const float h = std::sqrt(q.c2 * q.l2), R = std::sqrt((1 - q.c2) * q.l2);
-        const float base[3] = {q.c[0] + q.n[0] * h, q.c[1] + q.n[1] * h, q.c[2] + q.n[2] * h};
-        float mn[3], mx[3];
-        boxFromDisc(base, q.n, R, mn, mx);
-        for (int k = 0; k < 3; ++k) { mn[k] = std::min(mn[k], q.c[k]); mx[k] = std::max(mx[k], q.c[k]); }
-        put(mn, mx, 6, i);
-    }
     if (others) {
         HIP_TRY(c, hipMemcpy(static_cast<float4*>(c->primMin.p) + g.triangleNum, omin.data(), size_t(others) * 16, hipMemcpyHostToDevice));
         HIP_TRY(c, hipMemcpy(static_cast<float4*>(c->primMax.p) + g.triangleNum, omax.data(), size_t(others) * 16, hipMemcpyHostToDevice));
@@ -592,6 +594,59 @@ int lrl_destroy(LrlContext* c) {
     return LRL_OK;
 }
 
+// The caller's tree (pre-order 64-B own-box nodes) -> the two device layouts: 64-B inner records that hold both children's boxes, and the
+// four-wide compressed nodes.  Also lrl_scene_update_bvh.
+static int uploadCallerTree(LrlContext* c, const LrlSceneView* s, uint32_t& recCount) {
+    int rc = LRL_OK;
+    recCount = 1;
+    const uint32_t N = s->bvhNodeNum;
+    std::vector<uint32_t> recOf(N, 0);
+    for (uint32_t i = 0; i < N; ++i) if (s->bvh[i].bound.leftChild) recOf[i] = recCount++;
+    auto refOf = [&](uint32_t i) -> uint32_t {
+        const LrlBVHNode& n = s->bvh[i];
+        if (n.bound.leftChild) return recOf[i];
+        return LRL_REF_LEAF | (n.geometry << LRL_PRIM_TYPE_SHIFT) | (n.geometryNum & LRL_PRIM_INDEX_MASK);
+    };
+    auto asf = [](uint32_t v) { float f; std::memcpy(&f, &v, 4); return f; };
+    std::vector<float4> packed(size_t(recCount) * 4);
+    {   // record 0: virtual parent of the root
+        const LrlBVHNode& r = s->bvh[0];
+        packed[0] = make_float4(r.bound.min[0], r.bound.min[1], r.bound.min[2], asf(refOf(0)));
+        packed[1] = make_float4(r.bound.max[0], r.bound.max[1], r.bound.max[2], asf(LRL_REF_NONE));
+        packed[2] = make_float4(0, 0, 0, asf(0));
+        packed[3] = make_float4(0, 0, 0, asf(0));
+    }
+    for (uint32_t i = 0; i < N; ++i) {
+        const LrlBVHNode& n = s->bvh[i];
+        if (!n.bound.leftChild) continue;
+        float4* q = &packed[size_t(recOf[i]) * 4];
+        const LrlBVHNode& l = s->bvh[i + 1];
+        uint32_t own = n.geometry ? ((n.geometry << LRL_PRIM_TYPE_SHIFT) | (n.geometryNum & LRL_PRIM_INDEX_MASK)) : 0u;
+        q[0] = make_float4(l.bound.min[0], l.bound.min[1], l.bound.min[2], asf(refOf(i + 1)));
+        if (n.bound.rightChild) {
+            const LrlBVHNode& r = s->bvh[n.bound.rightChild];
+            q[1] = make_float4(l.bound.max[0], l.bound.max[1], l.bound.max[2], asf(refOf(uint32_t(n.bound.rightChild))));
+            q[2] = make_float4(r.bound.min[0], r.bound.min[1], r.bound.min[2], asf(own));
+            q[3] = make_float4(r.bound.max[0], r.bound.max[1], r.bound.max[2], asf(n.axis));
+        } else {
+            q[1] = make_float4(l.bound.max[0], l.bound.max[1], l.bound.max[2], asf(LRL_REF_NONE));
+            q[2] = make_float4(0, 0, 0, asf(own));
+            q[3] = make_float4(0, 0, 0, asf(n.axis));
+        }
+    }
+    rc = upload(c, c->nodes, packed.data(), packed.size() * sizeof(float4));
+    if (rc) return rc;
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    // the same tree collapsed to four children per node with 8-bit child boxes, for the FAST lean kernel (lrl_lean.inc)
+    uint32_t depth4 = 0;
+    std::vector<uint4> node4 = buildNode4(s, recOf, recCount, depth4);
+    c->node4Depth = depth4;
+    rc = upload(c, c->nodes32, node4.data(), node4.size() * sizeof(uint4));
+    if (rc) return rc;
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    return LRL_OK;
+}
+
 int lrl_scene_upload(LrlContext* c, const LrlSceneView* s) {
     if (c) { c->handoverThr.clear(); c->feedbackTick = 0; c->contIters = 0; }      // the hand-over thresholds start again with a new scene (feedback still in flight is the old scene's: dropped)
     if (!c || !s) return LRL_ERR_INVALID_ARG;
@@ -618,53 +673,7 @@ int lrl_scene_upload(LrlContext* c, const LrlSceneView* s) {
 
     // nodes: the reference's 64-B own-box records -> 64-B inner records that hold both children's boxes
     uint32_t recCount = 1;
-    if (!deviceBuild) {
-        const uint32_t N = s->bvhNodeNum;
-        std::vector<uint32_t> recOf(N, 0);
-        for (uint32_t i = 0; i < N; ++i) if (s->bvh[i].bound.leftChild) recOf[i] = recCount++;
-        auto refOf = [&](uint32_t i) -> uint32_t {
-            const LrlBVHNode& n = s->bvh[i];
-            if (n.bound.leftChild) return recOf[i];
-            return LRL_REF_LEAF | (n.geometry << LRL_PRIM_TYPE_SHIFT) | (n.geometryNum & LRL_PRIM_INDEX_MASK);
-        };
-        auto asf = [](uint32_t v) { float f; std::memcpy(&f, &v, 4); return f; };
-        std::vector<float4> packed(size_t(recCount) * 4);
-        {   // record 0: virtual parent of the root
-            const LrlBVHNode& r = s->bvh[0];
-            packed[0] = make_float4(r.bound.min[0], r.bound.min[1], r.bound.min[2], asf(refOf(0)));
-            packed[1] = make_float4(r.bound.max[0], r.bound.max[1], r.bound.max[2], asf(LRL_REF_NONE));
-            packed[2] = make_float4(0, 0, 0, asf(0));
-            packed[3] = make_float4(0, 0, 0, asf(0));
-        }
-        for (uint32_t i = 0; i < N; ++i) {
-            const LrlBVHNode& n = s->bvh[i];
-            if (!n.bound.leftChild) continue;
-            float4* q = &packed[size_t(recOf[i]) * 4];
-            const LrlBVHNode& l = s->bvh[i + 1];
-            uint32_t own = n.geometry ? ((n.geometry << LRL_PRIM_TYPE_SHIFT) | (n.geometryNum & LRL_PRIM_INDEX_MASK)) : 0u;
-            q[0] = make_float4(l.bound.min[0], l.bound.min[1], l.bound.min[2], asf(refOf(i + 1)));
-            if (n.bound.rightChild) {
-                const LrlBVHNode& r = s->bvh[n.bound.rightChild];
-                q[1] = make_float4(l.bound.max[0], l.bound.max[1], l.bound.max[2], asf(refOf(uint32_t(n.bound.rightChild))));
-                q[2] = make_float4(r.bound.min[0], r.bound.min[1], r.bound.min[2], asf(own));
-                q[3] = make_float4(r.bound.max[0], r.bound.max[1], r.bound.max[2], asf(n.axis));
-            } else {
-                q[1] = make_float4(l.bound.max[0], l.bound.max[1], l.bound.max[2], asf(LRL_REF_NONE));
-                q[2] = make_float4(0, 0, 0, asf(own));
-                q[3] = make_float4(0, 0, 0, asf(n.axis));
-            }
-        }
-        rc = upload(c, c->nodes, packed.data(), packed.size() * sizeof(float4));
-        if (rc) return rc;
-        HIP_TRY(c, hipStreamSynchronize(c->stream));
-        // the same tree collapsed to four children per node with 8-bit child boxes, for the FAST lean kernel (lrl_lean.inc)
-        uint32_t depth4 = 0;
-        std::vector<uint4> node4 = buildNode4(s, recOf, recCount, depth4);
-        c->node4Depth = depth4;
-        rc = upload(c, c->nodes32, node4.data(), node4.size() * sizeof(uint4));
-        if (rc) return rc;
-        HIP_TRY(c, hipStreamSynchronize(c->stream));
-    }
+    if (!deviceBuild && (rc = uploadCallerTree(c, s, recCount))) return rc;
     if (!deviceBuild && c->tuning.debug) std::fprintf(stderr, "lrl: binary nodes %u (depth %u), four-wide tree depth %u\n", s->bvhNodeNum, depth, c->node4Depth);
     if (deviceBuild) {
         if ((rc = ensure(c, c->primMin, size_t(primTotal) * 16))) return rc;
@@ -796,6 +805,72 @@ int lrl_scene_update_triangles_noalloc(LrlContext* c, uint32_t first, uint32_t c
     if (c->deviceBuilt)      // keep the boxes current for lrl_scene_rebuild_bvh
         HIP_TRY(c, lrl_launch_triangle_boxes(stageTris, first, count, static_cast<float4*>(c->primMin.p), static_cast<float4*>(c->primMax.p), c->stream));
     HIP_TRY(c, hipStreamSynchronize(c->stream));   // the caller's array is borrowed only for this call; the staging area is free again
+    return LRL_OK;
+}
+
+int lrl_scene_update_primitives(LrlContext* c, uint32_t kind, uint32_t first, uint32_t count, const void* records) {
+    if (!c || (count && !records)) return LRL_ERR_INVALID_ARG;
+    if (!c->haveScene) return fail(c, LRL_ERR_NO_SCENE, "no scene uploaded");
+    const LrlGeometryNum& g = c->num;
+    DevBuf* buf = nullptr;
+    uint32_t have = 0;
+    size_t size = 0;
+    switch (kind) {
+        case LRL_PRIM_SPHERE: buf = &c->spheres; have = g.sphereNum; size = sizeof(LrlSphere); break;
+        case LRL_PRIM_CIRCLE: buf = &c->circles; have = g.circleNum; size = sizeof(LrlCircle); break;
+        case LRL_PRIM_CYLINDER: buf = &c->cylinders; have = g.cylinderNum; size = sizeof(LrlCylinder); break;
+        case LRL_PRIM_CONE: buf = &c->cones; have = g.coneNum; size = sizeof(LrlCone); break;
+        case LRL_PRIM_LIGHT: buf = &c->lights; have = g.pointLightNum; size = sizeof(LrlPointLight); break;
+        default: return fail(c, LRL_ERR_INVALID_ARG, "kind must be LRL_PRIM_SPHERE, _CIRCLE, _CYLINDER, _CONE or _LIGHT");
+    }
+    if (uint64_t(first) + count > have) return fail(c, LRL_ERR_INVALID_ARG, "primitive range out of bounds");
+    if (!count) return LRL_OK;
+    HIP_TRY(c, hipSetDevice(c->device));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));      // frames in flight read these records
+    HIP_TRY(c, hipMemcpy(static_cast<char*>(buf->p) + size_t(first) * size, records, size_t(count) * size, hipMemcpyHostToDevice));
+    if (kind == LRL_PRIM_LIGHT) return LRL_OK;
+    const char* const rec = static_cast<const char*>(records);
+    for (uint32_t i = 0; i < count; ++i) {               // every geometry record ends with its Color
+        const LrlColor& col = *reinterpret_cast<const LrlColor*>(rec + size_t(i + 1) * size - sizeof(LrlColor));
+        if (transmits(col)) c->hasTransmission = true;
+    }
+    if (kind == LRL_PRIM_CIRCLE) {                       // CirclePre on the new records only (normalising twice is not the identity)
+        HIP_TRY(c, lrl_launch_circle_pre(static_cast<LrlCircle*>(c->circles.p) + first, count, c->stream));
+        HIP_TRY(c, hipStreamSynchronize(c->stream));
+    }
+    if (c->deviceBuilt) {                                // their leaf boxes, for lrl_scene_rebuild_bvh
+        const uint32_t before[7] = {0, 0, 0, 0, g.sphereNum, g.sphereNum + g.circleNum, g.sphereNum + g.circleNum + g.cylinderNum};
+        auto asf = [](uint32_t v) { float f; std::memcpy(&f, &v, 4); return f; };
+        std::vector<float4> mnv(count), mxv(count);
+        for (uint32_t i = 0; i < count; ++i) {
+            float mn[3], mx[3];
+            otherBox(kind, records, i, mn, mx);
+            mnv[i] = make_float4(mn[0], mn[1], mn[2], asf((kind << LRL_PRIM_TYPE_SHIFT) | (first + i)));
+            mxv[i] = make_float4(mx[0], mx[1], mx[2], 0.0f);
+        }
+        const size_t at = size_t(g.triangleNum) + before[kind] + first;
+        HIP_TRY(c, hipMemcpy(static_cast<float4*>(c->primMin.p) + at, mnv.data(), size_t(count) * 16, hipMemcpyHostToDevice));
+        HIP_TRY(c, hipMemcpy(static_cast<float4*>(c->primMax.p) + at, mxv.data(), size_t(count) * 16, hipMemcpyHostToDevice));
+    }
+    return LRL_OK;
+}
+
+int lrl_scene_update_bvh(LrlContext* c, const LrlBVHNode* bvh, uint32_t bvhNodeNum) {
+    if (!c || !bvh) return LRL_ERR_INVALID_ARG;
+    if (!c->haveScene) return fail(c, LRL_ERR_NO_SCENE, "no scene uploaded");
+    if (c->deviceBuilt) return fail(c, LRL_ERR_INVALID_ARG, "the library built this scene's tree: lrl_scene_rebuild_bvh");
+    HIP_TRY(c, hipSetDevice(c->device));
+    LrlSceneView v{};
+    v.num = c->num; v.bvh = bvh; v.bvhNodeNum = bvhNodeNum;
+    uint32_t depth = 0, recCount = 1;
+    int rc = validateBVH(c, &v, depth);
+    if (rc) return rc;
+    HIP_TRY(c, hipStreamSynchronize(c->stream));      // frames in flight walk the old tree
+    c->haveScene = false;                             // (a failed upload leaves no half-written tree in use)
+    if ((rc = uploadCallerTree(c, &v, recCount))) return rc;
+    c->nodeNum = bvhNodeNum; c->recNum = recCount; c->bvhDepth = depth;
+    c->handoverThr.clear(); c->feedbackTick = 0; c->contIters = 0;
+    c->haveScene = true;
     return LRL_OK;
 }
 

@@ -21,6 +21,7 @@ EXPORTS = [
     "lrl_render", "lrl_render_async", "lrl_sync", "lrl_get_counters", "lrl_last_kernel_ms", "lrl_scene_device_bytes",
     "lrl_timing_begin", "lrl_timing_end", "lrl_water_init", "lrl_water_step", "lrl_water_read", "lrl_scene_rebuild_bvh", "lrl_quantize_rgba8", "lrl_get_tuning", "lrl_set_tuning",
     "lrl_scene_update_triangles_noalloc", "lrl_shard_rows", "lrl_scene_info", "lrl_last_render_info",
+    "lrl_scene_update_primitives", "lrl_scene_update_bvh",
 ]
 
 
@@ -37,6 +38,8 @@ def lib():
         L.lrl_scene_upload.argtypes = [C.c_void_p, C.POINTER(abi.SceneView)]
         L.lrl_scene_update_triangles.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32, C.c_void_p]
         L.lrl_scene_update_triangles_noalloc.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32, C.c_void_p]
+        L.lrl_scene_update_primitives.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint32, C.c_void_p]
+        L.lrl_scene_update_bvh.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32]
         L.lrl_scene_read_triangles_gpu.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32, C.c_void_p]
         L.lrl_scene_read_circles.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32, C.c_void_p]
         L.lrl_set_camera.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32]
@@ -142,6 +145,22 @@ class Tracer:
         """lrl_scene_update_triangles_noalloc: the same update through the library's static staging array (allocates nothing)."""
         tris = np.ascontiguousarray(tris, dtype=abi.TRIANGLE)
         self._ck(self._L.lrl_scene_update_triangles_noalloc(self._ctx, first, tris.shape[0], tris.ctypes.data_as(C.c_void_p)))
+
+    def update_primitives(self, kind, first, records):
+        """lrl_scene_update_primitives: records [first, first + len) of one class (abi.PRIM_SPHERE .. PRIM_CONE, PRIM_LIGHT) in place."""
+        dt = {abi.PRIM_SPHERE: abi.SPHERE, abi.PRIM_CIRCLE: abi.CIRCLE, abi.PRIM_CYLINDER: abi.CYLINDER, abi.PRIM_CONE: abi.CONE,
+              abi.PRIM_LIGHT: abi.POINTLIGHT}.get(kind)
+        records = np.ascontiguousarray(records, dtype=dt) if dt is not None else np.ascontiguousarray(records)
+        self._ck(self._L.lrl_scene_update_primitives(self._ctx, C.c_uint32(kind), C.c_uint32(first), C.c_uint32(records.shape[0]),
+                                                     records.ctypes.data_as(C.c_void_p)))
+
+    def update_bvh(self, bvh, node_num=None):
+        """lrl_scene_update_bvh: a new caller-built tree over the same primitives.  bvh: a numpy BVHNODE array, or an address + node_num."""
+        if node_num is None:
+            bvh = np.ascontiguousarray(bvh, dtype=abi.BVHNODE)
+            self._ck(self._L.lrl_scene_update_bvh(self._ctx, bvh.ctypes.data_as(C.c_void_p), C.c_uint32(bvh.shape[0])))
+        else:
+            self._ck(self._L.lrl_scene_update_bvh(self._ctx, C.c_void_p(bvh), C.c_uint32(node_num)))
 
     def read_triangles_gpu(self, first, count):
         out = np.zeros(count, dtype=abi.TRIANGLE_GPU)

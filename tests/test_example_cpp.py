@@ -52,6 +52,65 @@ def test_headless_example_writes_the_reference_frame(name, args, resdir):
     assert "decayOrigin (0, 0, 0, 1)" in r.stdout          # the eye is in air: DecayOriginPre / DecayOrigin ran
 
 
+def read_ppm(path):
+    b = open(path, "rb").read()
+    magic, dims, maxv, rest = b.split(b"\n", 3)
+    w, h = (int(x) for x in dims.split())
+    assert magic == b"P6" and maxv == b"255"
+    return np.frombuffer(rest, dtype=np.uint8, count=w * h * 3).reshape(h, w, 3)[::-1].copy()      # row 0 = bottom
+
+
+def read_pfm(path):
+    b = open(path, "rb").read()
+    magic, dims, scale, rest = b.split(b"\n", 3)
+    w, h = (int(x) for x in dims.split())
+    assert magic == b"PF" and float(scale) < 0           # little-endian
+    return np.frombuffer(rest, dtype="<f4", count=w * h * 3).reshape(h, w, 3).copy()                # rows bottom-up already
+
+
+@pytest.mark.gpu
+def test_headless_example_moves_spheres_and_dumps_ppm_pfm():
+    """--move: Movement::run before every frame through lrl_scene_update_primitives + lrl_scene_update_bvh (host tree) or
+    + lrl_scene_rebuild_bvh (library's tree), from the compiled C++ caller.  After three frames the spheres have moved by
+    sin 0.1 + sin 0.2 + sin 0.3: the frame must equal the tracer's frame of a scene assembled with the spheres there.  The PPM and
+    PFM dumps (lrl/Image.hpp) hold the same frame as the BMP: byte for byte, and float values that quantise to those bytes."""
+    from raytracing_amd import abi, tracer as T
+    import ctypes as C
+    W = H = 192
+    m = scenes.bvh_default(builder="reference")
+    v = m.scene_view()
+    sph = np.frombuffer((C.c_uint8 * (v.num.sphereNum * 128)).from_address(v.spheres), dtype=abi.SPHERE)
+    for k in (1, 2, 3):                                   # float arithmetic as the example's: t += 0.1f; y += sin(t)
+        t = np.float32(0)
+        for _ in range(k):
+            t = np.float32(t + np.float32(0.1))
+        s = np.float32(np.sin(np.float32(t)))
+        sph["sphere"][0, 1] = np.float32(sph["sphere"][0, 1] + s)
+        sph["sphere"][1, 1] = np.float32(sph["sphere"][1, 1] + s)
+    m.data_init("reference")
+    tr = T.Tracer(0)
+    try:
+        tr.scene_upload(m.scene_view())
+        tr.set_camera(m.camera(H), W, H)
+        tr.set_decay_origin((0, 0, 0, 1))
+        want = quantised(tr.render(max_depth=10)[0][..., :3])
+    finally:
+        tr.close()
+    for extra in ([], ["--device-bvh"]):
+        with tempfile.TemporaryDirectory() as td:
+            out, ppm, pfm = (os.path.join(td, n) for n in ("f.bmp", "f.ppm", "f.pfm"))
+            r = subprocess.run([EXE, scenes.BVH_RESOURCES, out, "--size", str(W), str(H), "--frames", "3", "--move", "--ppm", ppm, "--pfm", pfm] + extra,
+                               capture_output=True, text=True, timeout=120)
+            assert r.returncode == 0, r.stderr + r.stdout
+            img, img_ppm, img_pfm = read_bmp(out), read_ppm(ppm), read_pfm(pfm)
+        assert np.array_equal(img, img_ppm)
+        assert np.array_equal(quantised(img_pfm), img)
+        assert np.isfinite(img_pfm).mean() > 0.999 and img_pfm.max() > 1.0       # unclamped values survive in the float dump
+        d = np.abs(img.astype(np.int16) - want.astype(np.int16))
+        # sinf of the C library against numpy's: the sphere centres may differ in the last bit, a byte here and there with them
+        assert (d > 1).any(axis=-1).mean() <= 1e-3, (extra, float((d > 1).any(axis=-1).mean()), int(d.max()))
+
+
 def test_cmake_builds_libraries_and_example():
     """north_star's "headless Linux CMake build": configure + build of CMakeLists.txt (about 20 s on 8 cores), then the C-ABI library it
     produced exports what include/lrl_trace.h declares."""

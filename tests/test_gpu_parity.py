@@ -872,3 +872,75 @@ def test_c1_at_1024_vs_llvmpipe_golden(tracer, default_model, mode):
     # moves its tile's sum by up to 0.5)
     bar = (RMSE_PARITY if mode == abi.MODE_PARITY else FAST_RMSE) * 16
     assert np.sqrt((err ** 2).mean()) <= bar, (mode, float(np.sqrt((err ** 2).mean())), float(err.max()), same)
+
+
+def _host_records(ptr, n, dt):
+    """A writable numpy view of one of the host model's own arrays (no copy): the test moves primitives the way Movement::run does."""
+    import ctypes as C
+    return np.frombuffer((C.c_uint8 * (n * dt.itemsize)).from_address(ptr), dtype=dt)
+
+
+def test_moving_spheres_and_lights_like_movement_run(tracer):
+    """Movement::run (/root/reference/BVH/BVH.cpp:187-205): two spheres and a point light move, then model.dataInit() uploads the
+    scene again.  Here: lrl_scene_update_primitives on the moved records + lrl_scene_update_bvh with the tree the host builder makes
+    for the new positions (caller's tree), or + lrl_scene_rebuild_bvh (library's tree).  The frame must be the one a fresh upload of
+    the moved scene gives, bit for bit, in PARITY and FAST; the caller's-tree frame is also checked against the oracle."""
+    from raytracing_amd import tracer as T
+    g = load_golden("bvh_viewB_256")
+    W, H = 192, 192
+    m = scenes.bvh_default(builder="reference")
+    v = m.scene_view()
+    tracer.scene_upload(v)
+    tracer.set_camera(g["trans"], W, H)
+    tracer.set_decay_origin((0, 0, 0, 1))
+    before = tracer.render(max_depth=6)
+    dev = T.Tracer(0)                                     # the same scene on a tree of the library's own
+    fresh = T.Tracer(0)
+    try:
+        vd = m.scene_view(); vd.bvh = None; vd.bvhNodeNum = 0
+        dev.scene_upload(vd)
+        dev.set_camera(g["trans"], W, H); dev.set_decay_origin((0, 0, 0, 1))
+        for step in range(2):
+            t = 0.1 * (step + 1) * 7                      # (a visible move: seven of the reference's 0.1 steps at once)
+            sph = _host_records(v.spheres, v.num.sphereNum, abi.SPHERE)
+            lights = _host_records(v.pointLights, v.num.pointLightNum, abi.POINTLIGHT)
+            sph["sphere"][0, 1] += np.float32(np.sin(t)); sph["sphere"][1, 1] += np.float32(np.sin(t))      # sphereRun
+            lights["p"][0, 0] = np.float32(3 * np.sin(t)); lights["p"][0, 2] += np.float32(0.2 * np.sin(t))  # pointLightRun
+            m.data_init("reference")                      # model.dataInit(): the host builder's tree for the new positions
+            v = m.scene_view()
+            sph = _host_records(v.spheres, v.num.sphereNum, abi.SPHERE)
+            lights = _host_records(v.pointLights, v.num.pointLightNum, abi.POINTLIGHT)
+            tracer.update_primitives(abi.PRIM_SPHERE, 0, sph[:2])
+            tracer.update_primitives(abi.PRIM_LIGHT, 0, lights[:1])
+            tracer.update_bvh(v.bvh, v.bvhNodeNum)
+            dev.update_primitives(abi.PRIM_SPHERE, 0, sph[:2])
+            dev.update_primitives(abi.PRIM_LIGHT, 0, lights[:1])
+            dev.rebuild_bvh()
+            fresh.scene_upload(v)
+            fresh.set_camera(g["trans"], W, H); fresh.set_decay_origin((0, 0, 0, 1))
+            for mode in (abi.MODE_PARITY, abi.MODE_FAST):
+                got, want = tracer.render(max_depth=6, mode=mode), fresh.render(max_depth=6, mode=mode)
+                assert np.array_equal(got[1], want[1]) and np.array_equal(got[0].view(np.uint32), want[0].view(np.uint32)), (step, mode)
+            assert not np.array_equal(got[1], before[1])                      # something did move
+            oimg, ohits, _ = O.render(v, g["trans"], W, H, max_depth=6, threads=8)
+            par = tracer.render(max_depth=6)
+            assert (par[1] == ohits).all(axis=-1).mean() >= ID_BAR
+            check_image(par[0], oimg, abi.MODE_PARITY, ("moved spheres", step))
+            # the library's own tree: against a fresh upload without a tree
+            vf = m.scene_view(); vf.bvh = None; vf.bvhNodeNum = 0
+            fresh.scene_upload(vf)
+            for mode in (abi.MODE_PARITY, abi.MODE_FAST):
+                got, want = dev.render(max_depth=6, mode=mode), fresh.render(max_depth=6, mode=mode)
+                assert np.array_equal(got[1], want[1]) and np.array_equal(got[0].view(np.uint32), want[0].view(np.uint32)), ("device", step, mode)
+            # (another tree visits the scene's coincident discs in another order: exact ties, as in test_device_built_bvh_vs_llvmpipe_golden)
+            assert (dev.render(max_depth=6)[1] == ohits).all(axis=-1).mean() >= 0.9995
+        # what is refused
+        for bad in (lambda: tracer.update_primitives(abi.PRIM_SPHERE, v.num.sphereNum, sph[:1]),
+                    lambda: tracer.update_primitives(2, 0, sph[:1]),
+                    lambda: dev.update_bvh(v.bvh, v.bvhNodeNum),
+                    lambda: tracer.update_bvh(v.bvh, 1)):
+            with pytest.raises(T.TraceError):
+                bad()
+        assert np.array_equal(tracer.render(max_depth=6)[1], par[1])          # a refused update leaves the scene as it was
+    finally:
+        dev.close(); fresh.close()
