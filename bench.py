@@ -340,7 +340,8 @@ def main():
 def run(a, torch, dist, sharding, rank, local_rank, world, dev, rehearse):
     scaling = a.scaling or WORKLOADS[a.workload][8]
     steps = a.steps or {"c1": 50, "c2": 50, "c3": 5, "c4": 3, "c5": 5}[a.workload]
-    warmup = a.warmup if a.warmup >= 0 else {"c1": 5, "c2": 5, "c3": 2, "c4": 1, "c5": 2}[a.workload]
+    # (at least eight: three frames settle the hand-over thresholds, four are timed by the library itself to decide on triangle trips)
+    warmup = a.warmup if a.warmup >= 0 else {"c1": 10, "c2": 10, "c3": 8, "c4": 8, "c5": 8}[a.workload]
     wl = Workload(a, a.workload, local_rank, world, rank, scaling)
     wl.count()
     W, H = wl.W, wl.H
@@ -474,7 +475,7 @@ def run(a, torch, dist, sharding, rank, local_rank, world, dev, rehearse):
                    "bvh_wide_depth": wl.info["wideDepth"], "arithmetic": a.mode, "parallelism": par,
                    "rays_per_frame": int(rays_all), "host_scene_build_s": round(wl.build_s, 2), "scene_upload_s": round(wl.upload_s, 2),
                    "device_scene_bytes": wl.tr.scene_device_bytes(),
-                   "schedule": {k: rinfo[k] for k in ("passes", "batch", "iterations", "compactFrom", "groupLanes", "frontierEntries", "contSlots", "coopFetch", "streamWords")}},
+                   "schedule": {k: rinfo[k] for k in ("passes", "batch", "iterations", "compactFrom", "groupLanes", "frontierEntries", "contSlots", "coopFetch", "streamWords", "phasedTrips")}},
         "roofline": wl.roofline(kernel_ms, launches, frame_ms, traffic, valu),
     }
     if not a.no_cpu_baseline and world == 1:
@@ -494,7 +495,7 @@ def roofline_c5(a, local_rank, torch, dev):
     wl = Workload(b, "c5", local_rank, 1, 0, "weak")
     wl.count()
     out = torch.empty((wl.H, wl.W, 4), dtype=torch.float32, device=dev)
-    for _ in range(2):
+    for _ in range(8):
         wl.render_into(out.data_ptr())
     wl.tr.sync()
     wl.tr.timing_begin()

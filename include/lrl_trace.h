@@ -164,6 +164,9 @@ typedef struct LrlTuning {
                                  /*   (tools/probes/hbm_gather.hip); the rays of the measured scenes are more coherent and lose ~12 %.  0: off   */
     uint32_t streamWords;        /* > 1: the lean trace kernel runs as waves that own this many 64-ray words of a launch and hand the next rays  */
     uint32_t refillMin;          /*   of their words to idle lanes whenever at least refillMin (16) lanes are idle; 0 / 1: one word per wave        */
+    uint32_t phasedTrips;        /* triangle trips of the lean kernel: a trip on which many lanes hold a triangle runs the triangle block alone and the  */
+                                 /*   node lanes wait with their record (same frame bit for bit; faster on flat trees and incoherent rays, slower on     */
+                                 /*   coherent ones): 1 on, 2 off, 0 = the library times one frame each way per scene and frame shape and keeps the faster */
     uint32_t debug;              /* 1: per-frame diagnostics on stderr (adds host waits); 2: a line around every HIP call of the   */
                                  /*   render path instead (no added waits); 3: both                                                */
 } LrlTuning;
@@ -280,6 +283,7 @@ typedef struct LrlRenderInfo {       /* of the last wavefront-pipeline render */
     uint32_t contSlots, contStride;
     uint32_t coopFetch;      /* 1: the trace kernels fetched records with four lanes to a record                            */
     uint32_t streamWords;    /* words per wave of the lean kernel with lane refill (0: one-word waves)                      */
+    uint32_t phasedTrips;    /* 1: the lean kernel ran with triangle trips                                                  */
     uint32_t handoverTrips[8]; /* thresholds of the first eight segments as the last pass used them (0: no hand-over)      */
 } LrlRenderInfo;
 int lrl_last_render_info(const LrlContext* ctx, LrlRenderInfo* out);

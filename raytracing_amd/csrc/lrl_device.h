@@ -193,7 +193,7 @@ struct WFrame {
 LRL_WF_DECLARE(lrl_parity)
 LRL_WF_DECLARE(lrl_fast)
 namespace lrl_fast {
-hipError_t wfLaunchTraceLean(const KScene& sc, const WFrame& wf, bool sparse, bool compact, bool coop, uint32_t streamWords, uint32_t refillMin, hipStream_t stream);   // sparse: few rays in many words (larger workgroups)
+hipError_t wfLaunchTraceLean(const KScene& sc, const WFrame& wf, bool sparse, bool compact, bool coop, bool phased, uint32_t streamWords, uint32_t refillMin, hipStream_t stream);   // phased: one block a trip   // sparse: few rays in many words (larger workgroups)
 hipError_t wfLaunchTraceSwarm(const KScene& sc, const WFrame& wf, uint32_t waves, uint32_t group, bool coop, hipStream_t stream);   // coop: four lanes to a record fetch (lrl_lean.inc)
 }
 

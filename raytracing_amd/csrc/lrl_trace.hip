@@ -82,6 +82,13 @@ struct LrlContext {
     uint32_t* contHostDev = nullptr;    // the device's address of the same memory
     uint32_t contSlotsInFlight = 0;     // hand-over slots of the pass whose feedback is in flight
     hipEvent_t evCont = nullptr;
+    // triangle trips of the lean kernel (lrl_lean.inc, PH): decided per scene and frame shape by timing one frame each way
+    struct PhasedTrial {
+        int state = 0;                  // 0..2: frames that let the hand-over thresholds settle; 3..6: timed frames, without / with / without / with; 7: waiting for the events; 8: decided
+        uint64_t signature = 0;         // frame shape the trial belongs to
+        bool choice = false;
+        hipEvent_t ev[8] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};      // start, end of the four timed frames
+    } phasedTrial;
     hipEvent_t evLastRender = nullptr;  // recorded behind every render: a render on another stream waits for it (the arena is shared)
     hipStream_t lastRenderStream = nullptr;
     bool renderedOnce = false;
@@ -487,7 +494,7 @@ hipError_t noallocScratchFor(int device, void** out) {
 LrlTuning defaultTuning() {
     LrlTuning t{};
     t.handoverEarly = 48; t.handoverLate = 16; t.handoverListLen = 0;
-    t.adapt = 1; t.groupLanes = 0; t.contSlots = 0; t.groupCapX = 0; t.sparseFrom = 5; t.compactFrom = -1; t.coopFetch = 0; t.streamWords = 0; t.refillMin = 16;
+    t.adapt = 1; t.groupLanes = 0; t.contSlots = 0; t.groupCapX = 0; t.sparseFrom = 5; t.compactFrom = -1; t.coopFetch = 0; t.streamWords = 0; t.refillMin = 16; t.phasedTrips = 0;
     t.workLow = 12.0f; t.pollLag = 1; t.traceRef = 0; t.batchSlots = 0; t.debug = 0;
     return t;
 }
@@ -540,6 +547,7 @@ int lrl_create(int device, LrlContext** out) {
               hipEventCreateWithFlags(&c->evCont, hipEventDisableTiming) == hipSuccess &&
               hipEventCreateWithFlags(&c->evLastRender, hipEventDisableTiming) == hipSuccess;
     for (hipEvent_t& e : c->evIter) ok = ok && hipEventCreateWithFlags(&e, hipEventDisableTiming) == hipSuccess;
+    for (hipEvent_t& e : c->phasedTrial.ev) ok = ok && hipEventCreate(&e) == hipSuccess;
     ok = ok && noallocScratchFor(device, &c->noallocScratch) == hipSuccess;
     if (ok) c->noallocMat.assign(LRL_NOALLOC_MAX_TRIANGLES, 0u);      // host side of the material indices, so that the entry point allocates nothing
     if (!ok) {
@@ -566,8 +574,10 @@ int lrl_set_tuning(LrlContext* c, const LrlTuning* t) {
     if ((t->groupCapX > 2 && t->groupCapX != 4) || t->compactFrom < -1 || !(t->workLow >= 0.0f)) return fail(c, LRL_ERR_INVALID_ARG, "groupCapX must be 0, 1, 2 or 4, compactFrom >= -1, workLow >= 0");
     if (t->contSlots > (1u << 22)) return fail(c, LRL_ERR_LIMIT, "contSlots > 2^22");
     if (t->coopFetch > 1) return fail(c, LRL_ERR_INVALID_ARG, "coopFetch must be 0 or 1");
+    if (t->phasedTrips > 2) return fail(c, LRL_ERR_INVALID_ARG, "phasedTrips must be 0 (by launch size), 1 (on) or 2 (off)");
     if (t->streamWords > 4096 || t->refillMin > 64) return fail(c, LRL_ERR_INVALID_ARG, "streamWords <= 4096, refillMin <= 64");
     c->tuning = *t;
+    c->phasedTrial.state = 0; c->phasedTrial.signature = 0;
     c->handoverThr.clear();      // the adaptive thresholds start again from the new base values
     c->feedbackTick = 0;
     c->contIters = 0;
@@ -587,6 +597,7 @@ int lrl_destroy(LrlContext* c) {
     if (c->evCont) (void)hipEventDestroy(c->evCont);
     if (c->evLastRender) (void)hipEventDestroy(c->evLastRender);
     for (hipEvent_t e : c->evIter) if (e) (void)hipEventDestroy(e);
+    for (hipEvent_t e : c->phasedTrial.ev) if (e) (void)hipEventDestroy(e);
     if (c->evStart) (void)hipEventDestroy(c->evStart);
     if (c->evStop) (void)hipEventDestroy(c->evStop);
     if (c->stream) (void)hipStreamDestroy(c->stream);
@@ -648,7 +659,7 @@ static int uploadCallerTree(LrlContext* c, const LrlSceneView* s, uint32_t& recC
 }
 
 int lrl_scene_upload(LrlContext* c, const LrlSceneView* s) {
-    if (c) { c->handoverThr.clear(); c->feedbackTick = 0; c->contIters = 0; }      // the hand-over thresholds start again with a new scene (feedback still in flight is the old scene's: dropped)
+    if (c) { c->handoverThr.clear(); c->feedbackTick = 0; c->contIters = 0; c->phasedTrial.state = 0; c->phasedTrial.signature = 0; }      // the hand-over thresholds start again with a new scene (feedback still in flight is the old scene's: dropped)
     if (!c || !s) return LRL_ERR_INVALID_ARG;
     HIP_TRY(c, hipSetDevice(c->device));
     const LrlGeometryNum& g = s->num;
@@ -870,6 +881,7 @@ int lrl_scene_update_bvh(LrlContext* c, const LrlBVHNode* bvh, uint32_t bvhNodeN
     if ((rc = uploadCallerTree(c, &v, recCount))) return rc;
     c->nodeNum = bvhNodeNum; c->recNum = recCount; c->bvhDepth = depth;
     c->handoverThr.clear(); c->feedbackTick = 0; c->contIters = 0;
+    c->phasedTrial.state = 0; c->phasedTrial.signature = 0;
     c->haveScene = true;
     return LRL_OK;
 }
@@ -1034,6 +1046,35 @@ static int renderWavefront(LrlContext* c, const LrlRenderParams* p, const KScene
     // per lane bound it: tools/probes/hbm_gather.hip), but the rays of C5 are not that incoherent: 54.2 against 48.5 ms per frame (every kernel
     // of the frame ~15 % slower: idle lanes fetch too, 8 shuffles + 16 swaps a trip).  Off unless asked for.
     const bool coop = tn.coopFetch == 1;
+    // Triangle trips (lrl_lean.inc, PH): -7 % on the Pool and -3 % on C5, +3-5 % on the coherent mirror rays of C2 / C4, and nothing the host knows
+    // beforehand tells the two apart.  The frames are the same bit for bit either way, so the library times frames each way (events on the
+    // caller's stream, read back without waiting) and keeps the faster for this scene and frame shape (two frames each way, alternating, after three that let the thresholds settle).  phasedTrips = 1 / 2 pins it.
+    LrlContext::PhasedTrial& trial = c->phasedTrial;
+    hipEvent_t trialEnd = nullptr;
+    bool phased = false;
+    if (special && !coop) {
+        if (tn.phasedTrips) phased = tn.phasedTrips == 1;
+        else {
+            const uint64_t signature = (Ppix64 * batch) ^ (uint64_t(f.sampleEnd - f.sampleBegin) << 32) ^ (uint64_t(p->maxDepth) << 48) ^ (uint64_t(p->flags & LRL_FLAG_DIFFUSE_BOUNCE) << 52) ^
+                                       (uint64_t(pool) << 57) ^ (uint64_t(L) << 58) ^ (ctr ? 1ull << 63 : 0ull);
+            if (trial.signature != signature) { trial.signature = signature; trial.state = 0; }
+            if (trial.state == 7 && hipEventQuery(trial.ev[7]) == hipSuccess) {
+                float t[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+                bool ok = true;
+                for (int i = 0; i < 4; ++i) ok = ok && hipEventElapsedTime(&t[i], trial.ev[2 * i], trial.ev[2 * i + 1]) == hipSuccess;
+                trial.choice = ok && t[1] + t[3] < 0.99f * (t[0] + t[2]);
+                trial.state = 8;
+                if (tn.debug == 1 || tn.debug >= 3) std::fprintf(stderr, "lrl: triangle trips %s (frames %.3f, %.3f ms with, %.3f, %.3f ms without)\n", trial.choice ? "on" : "off", t[1], t[3], t[0], t[2]);
+            }
+            if (trial.state >= 3 && trial.state <= 6) {
+                const int k = trial.state - 3;
+                phased = (k & 1) != 0;
+                CRUMB_TRY(c, "hipEventRecord(trial start)", hipEventRecord(trial.ev[2 * k], stream));
+                trialEnd = trial.ev[2 * k + 1];
+            } else if (trial.state == 8) phased = trial.choice;
+            if (trial.state < 7) ++trial.state;
+        }
+    }
     // lane refill (wfTraceLeanStreamKernel): waves that own streamWords words of a launch
     const uint32_t streamWords = tn.streamWords, refillMin = tn.refillMin ? std::min(64u, tn.refillMin) : 16u;
     if (swarmGroup != 8 && swarmGroup != 16 && swarmGroup != 32) swarmGroup = 64;
@@ -1178,7 +1219,7 @@ static int renderWavefront(LrlContext* c, const LrlRenderParams* p, const KScene
                 wf.contWork = contWorkAll + size_t(fi) * LRL_WORK_COUNTERS * 32;
                 const bool compact = compactFrom != 0 && iter >= compactFrom && iter < LRL_WF_MAX_ITERATIONS;
                 wf.listCount = listCounts + size_t(iter < LRL_WF_MAX_ITERATIONS ? iter : 0) * LRL_LIST_KINDS;
-                CRUMB_TRY(c, "trace (lean)", lrl_fast::wfLaunchTraceLean(k, wf, iter >= sparseFrom, compact, coop, streamWords, refillMin, stream));
+                CRUMB_TRY(c, "trace (lean)", lrl_fast::wfLaunchTraceLean(k, wf, iter >= sparseFrom, compact, coop, phased, streamWords, refillMin, stream));
                 if (wf.handoverTrips) CRUMB_TRY(c, "trace (hand-over)", lrl_fast::wfLaunchTraceSwarm(k, wf, std::min(contSlots, c->swarmGrid[fi]), swarmGroup, coop, stream));
             }
             else CRUMB_TRY(c, "trace", fast ? lrl_fast::wfLaunchTrace(k, wf, stream) : lrl_parity::wfLaunchTrace(k, wf, stream));
@@ -1221,13 +1262,14 @@ static int renderWavefront(LrlContext* c, const LrlRenderParams* p, const KScene
         }
         s += bsz;
     }
+    if (trialEnd) CRUMB_TRY(c, "hipEventRecord(trial end)", hipEventRecord(trialEnd, stream));
     if (e1) CRUMB_TRY(c, "hipEventRecord(frame end)", hipEventRecord(e1, stream));
     c->lastIterations = iterations;
     LrlRenderInfo& ri = c->renderInfo;
     ri = LrlRenderInfo{};
     ri.iterations = iterations; ri.passes = passIndex; ri.batch = batch;
     if (special) {
-        ri.compactFrom = compactFrom; ri.coopFetch = coop ? 1u : 0u; ri.streamWords = coop ? 0u : streamWords; ri.groupLanes = swarmGroup; ri.frontierEntries = swarmGroup == 64 ? LRL_SWARM_CAP : groupCap;
+        ri.compactFrom = compactFrom; ri.coopFetch = coop ? 1u : 0u; ri.streamWords = coop ? 0u : streamWords; ri.phasedTrips = phased ? 1u : 0u; ri.groupLanes = swarmGroup; ri.frontierEntries = swarmGroup == 64 ? LRL_SWARM_CAP : groupCap;
         ri.contSlots = contSlots; ri.contStride = contStride;
         for (uint32_t i = 0; i < 8; ++i) ri.handoverTrips[i] = handoverFits ? c->handoverThr[i] : 0u;
     }

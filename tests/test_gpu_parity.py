@@ -509,6 +509,42 @@ def test_lane_refill_changes_nothing(tracer, default_model, bunny0_model, pool_m
         tracer.set_tuning(base)
 
 
+def test_one_block_a_trip_changes_nothing(tracer, default_model, bunny0_model, pool_model):
+    """LrlTuning.phasedTrips: on trips where many lanes hold a triangle the lean kernel runs the triangle block alone and the node lanes
+    wait with their record.  A ray's own sequence of items does not change, so the frame is the same bit for bit: forced on and off here
+    over mask words, compacted lists and early hand-over, mirror and diffuse; then left to the library's own timed trial."""
+    base = tracer.get_tuning()
+    try:
+        gP = load_golden("pool_viewA_160")
+        for m, (W, H), tr, variant in ((default_model, (200, 168), default_model.camera(168), abi.VARIANT_BVH),
+                                       (bunny0_model, (320, 184), bunny0_model.camera(184), abi.VARIANT_BVH),
+                                       (pool_model, (160, 160), gP["trans"], abi.VARIANT_POOL)):
+            tracer.scene_upload(m.scene_view())
+            tracer.set_camera(tr, W, H)
+            tracer.set_decay_origin((0, 0, 0, 1))
+            for extra in ({}, {"compactFrom": 1}, {"adapt": 0, "handoverList": [6]}, {"sparseFrom": 1}):
+                for diffuse in (False, True):
+                    frames = {}
+                    for ph in (2, 1):
+                        tracer.set_tuning(base)
+                        tracer.set_tuning(phasedTrips=ph, **extra)
+                        frames[ph] = tracer.render(max_depth=5, mode=abi.MODE_FAST, variant=variant, diffuse=diffuse)
+                        assert tracer.last_render_info()["phasedTrips"] == (1 if ph == 1 else 0)
+                    assert np.array_equal(frames[1][1], frames[2][1]), (extra, diffuse, int((frames[1][1] != frames[2][1]).any(axis=-1).sum()))
+                    assert np.array_equal(frames[1][0].view(np.uint32), frames[2][0].view(np.uint32)), (extra, diffuse, image_stats(frames[1][0], frames[2][0]))
+            # left to itself (phasedTrips = 0) the library times one frame each way and settles: the same frame throughout
+            tracer.set_tuning(base)
+            assert tracer.get_tuning().phasedTrips == 0
+            seen = set()
+            for k in range(10):
+                got = tracer.render(max_depth=5, mode=abi.MODE_FAST, variant=variant, diffuse=True)
+                seen.add(tracer.last_render_info()["phasedTrips"])
+                assert np.array_equal(got[0].view(np.uint32), frames[2][0].view(np.uint32)) and np.array_equal(got[1], frames[2][1]), k
+            assert seen == {0, 1}                      # the trial ran both ways
+    finally:
+        tracer.set_tuning(base)
+
+
 def test_hand_over_kernels_agree(default_model, bunny0_model, pool_model):
     """FAST mode's continuation kernels (16 lanes per ray, and one wave per ray for deep trees) keep no visit order; the
     closest hit must come out all the same.  With a threshold of 4 trips nearly every ray goes through them: both must
