@@ -247,7 +247,9 @@ __global__ __launch_bounds__(256) void node4Kernel(const float4* __restrict__ re
         unit[a] = ldexp(1.0, e);
     }
     uint32_t bytes[6] = {0, 0, 0, 0, 0, 0};
-    uint32_t refs[4] = {LRL_REF_NONE, LRL_REF_NONE, LRL_REF_NONE, LRL_REF_NONE};
+    uint32_t refs[4] = {LRL_REF_EMPTY4, LRL_REF_EMPTY4, LRL_REF_EMPTY4, LRL_REF_EMPTY4};
+    for (int i = n; i < 4; ++i)
+        for (int a = 0; a < 3; ++a) bytes[a] |= LRL_EMPTY4_LO << (8 * i);      // empty slots: inverted boxes
     for (int i = 0; i < n; ++i) {
         const float lo[3] = {it[i].lo.x, it[i].lo.y, it[i].lo.z}, hi[3] = {it[i].hi.x, it[i].hi.y, it[i].hi.z};
         for (int a = 0; a < 3; ++a) {

@@ -42,6 +42,11 @@ static_assert(sizeof(LrlTriCold) == 32, "TriCold");
 #endif
 #define LRL_REF_NONE 0xffffffffu
 #define LRL_REF_LEAF 0x80000000u
+// An empty child slot of a FOUR-WIDE node: an inverted byte box (near planes 255, far planes 0), which fails the interval test by itself, so
+// the FAST kernels need no "is there a child" test per slot; its ref is a leaf of type 0, which no test block accepts: should rounding ever
+// let a ray through an inverted box (an origin 2^24 node sizes away), the lane spends one empty trip on it.
+#define LRL_REF_EMPTY4 LRL_REF_LEAF
+#define LRL_EMPTY4_LO 0xffu
 #define LRL_PRIM_TYPE_SHIFT 28
 #define LRL_PRIM_INDEX_MASK 0x0fffffffu
 #ifndef LRL_LDS_STACK_ENTRIES

@@ -227,7 +227,8 @@ std::vector<uchar4> bgrToRgbx(const uint8_t* bgr, size_t texels) {
 //   {origin.x, origin.y, origin.z, unit.x}                       origin = min corner of the items' boxes; unit = per-axis
 //                                                                length of one byte step, a power of two (as a float)
 //   {lo.x of items 0..3 (one byte each), lo.y, lo.z, hi.x}       box = origin + byte * unit, rounded outwards
-//   {hi.y, hi.z, ref0, ref1}  {ref2, ref3, unit.y, unit.z}       ref: LRL_REF_NONE, record index, or LRL_REF_LEAF | primitive
+//   {hi.y, hi.z, ref0, ref1}  {ref2, ref3, unit.y, unit.z}       ref: record index, LRL_REF_LEAF | primitive, or LRL_REF_EMPTY4 with an
+//                                                                inverted box (lo 255, hi 0) for an empty slot
 std::vector<uint4> buildNode4(const LrlSceneView* s, const std::vector<uint32_t>& recOf, uint32_t recCount, uint32_t& depthOut) {
     const LrlBVHNode* bvh = s->bvh;
     struct Item { bool inner; uint32_t ref; uint32_t boxOf; };      // inner: binary node index; else primitive bits; boxOf: binary node whose box bounds it
@@ -252,7 +253,7 @@ std::vector<uint4> buildNode4(const LrlSceneView* s, const std::vector<uint32_t>
         return dx * dy + dy * dz + dz * dx;
     };
     auto fb = [](float f) { uint32_t v; std::memcpy(&v, &f, 4); return v; };
-    std::vector<uint4> out(size_t(recCount) * 4, make_uint4(0, 0, LRL_REF_NONE, LRL_REF_NONE));
+    std::vector<uint4> out(size_t(recCount) * 4, make_uint4(0, 0, LRL_REF_EMPTY4, LRL_REF_EMPTY4));
     struct Work { uint32_t bin; bool virt; uint32_t depth; };
     std::vector<Work> work;
     work.push_back({0u, true, 0u});
@@ -303,7 +304,9 @@ std::vector<uint4> buildNode4(const LrlSceneView* s, const std::vector<uint32_t>
             unit[a] = std::ldexp(1.0, e);
         }
         uint32_t bytes[6] = {0, 0, 0, 0, 0, 0};      // lo.x lo.y lo.z hi.x hi.y hi.z, item i in byte i
-        uint32_t refs[4] = {LRL_REF_NONE, LRL_REF_NONE, LRL_REF_NONE, LRL_REF_NONE};
+        uint32_t refs[4] = {LRL_REF_EMPTY4, LRL_REF_EMPTY4, LRL_REF_EMPTY4, LRL_REF_EMPTY4};
+        for (int i = n; i < 4; ++i)
+            for (int a = 0; a < 3; ++a) bytes[a] |= LRL_EMPTY4_LO << (8 * i);      // empty slots: inverted boxes
         for (int i = 0; i < n; ++i) {
             const LrlBound& bb = bvh[items[i].boxOf].bound;
             for (int a = 0; a < 3; ++a) {
@@ -445,9 +448,9 @@ int runDeviceBuild(LrlContext* c, uint32_t prims, uint32_t& recCount, uint32_t& 
             hb[a] = uint32_t(std::min(255.0, std::ceil(ext / std::ldexp(1.0, e))));
         }
         n4[0] = make_uint4(o3[0], o3[1], o3[2], ex[0]);
-        n4[1] = make_uint4(0, 0, 0, hb[0]);
-        n4[2] = make_uint4(hb[1], hb[2], LRL_REF_LEAF | bits, LRL_REF_NONE);
-        n4[3] = make_uint4(LRL_REF_NONE, LRL_REF_NONE, ex[1], ex[2]);
+        n4[1] = make_uint4(0xffffff00u, 0xffffff00u, 0xffffff00u, hb[0]);      // slots 1..3 empty: inverted boxes
+        n4[2] = make_uint4(hb[1], hb[2], LRL_REF_LEAF | bits, LRL_REF_EMPTY4);
+        n4[3] = make_uint4(LRL_REF_EMPTY4, LRL_REF_EMPTY4, ex[1], ex[2]);
         HIP_TRY(c, hipMemcpy(c->nodes.p, rec, 64, hipMemcpyHostToDevice));
         HIP_TRY(c, hipMemcpy(c->nodes32.p, n4, 64, hipMemcpyHostToDevice));
         depth = 0;
