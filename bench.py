@@ -261,7 +261,11 @@ class Workload:
             # over this run's kernel time; a wave64 instruction occupies its 16-lane SIMD for four cycles
             peak = SIMDS * CLOCK_GHZ / 4.0                     # G wave-instructions per second
             r["valu_issue"] = {"wave_instructions_per_frame": int(valu), "achieved": round(valu / (kernel_ms * 1e-3) / 1e9, 2), "peak": round(peak, 1),
-                               "unit": "G wave-instructions/s", "busy_frac": round(valu / (kernel_ms * 1e-3) / 1e9 / peak, 4)}
+                               "unit": "G wave-instructions/s", "busy_frac": round(valu / (kernel_ms * 1e-3) / 1e9 / peak, 4),
+                               "note": "rocprof's VALUBusy convention: 4 cycles per wave64 instruction (what SQ_ACTIVE_INST_VALU itself counts).  "
+                                       "tools/probes/valu_rate.hip (profiles/r02_valu_rate_probe.txt): v_fma / v_max3 / v_cvt_f32_ubyte / v_cmp take 4.0-4.4 cycles, "
+                                       "v_mul_f32 / v_mov_b32 2.4-2.6, v_rcp_f32 8.3, so the figure is an upper estimate of the pipe's occupancy (the Pool's "
+                                       "mix reaches 1.19 by this convention)"}
         if resident and self.fetch_bytes:
             ach = self.fetch_bytes / (kernel_ms * 1e-3) / 1e9
             l1 = {"achieved": round(ach, 2), "peak": round(L1_GATHER_PEAK_GBPS, 1), "unit": "GB/s", "frac": round(ach / L1_GATHER_PEAK_GBPS, 5),
@@ -288,7 +292,8 @@ class Workload:
             if not resident:
                 r["gather_probe"] = GATHER_PROBE
         if not (0.0 < r["frac"] <= 1.0):
-            r["frac_note"] = "frac outside (0, 1]: the caches serve part of these bytes; see hbm_frac and work"
+            r["frac_note"] = ("frac above 1: lanes in step share records, which the per-lane L1 gather peak does not know (l1_note)" if r["bound"] == "l1"
+                              else "frac outside (0, 1]: the caches serve part of these bytes; see hbm_frac and work")
         return r
 
 

@@ -13,6 +13,18 @@ frames = int(frames)
 factor = float(os.environ.get("FETCH_FACTOR", "2"))
 if stats_dir != "-":
     shutil.copyfile(glob.glob(f"gpurun_out/{stats_dir}/**/*kernel_stats.csv", recursive=True)[0], f"profiles/{name}_kernel_stats.csv")
+def is_counting(kernel):
+    """The CNT template argument of a wf kernel: wfTraceKernel<CNT>, wfTraceLeanKernel<BW, CP, CNT, COOP, PH>, wfTraceLeanStreamKernel<CP, CNT>,
+    wfTraceSwarmKernel<CNT, COOP>, wfTraceGroupKernel<G, CAPX, CNT>, wfGenerateKernel<CNT>, wfShadeKernel<POOL, CNT>."""
+    if "<" not in kernel:
+        return False
+    name, args = kernel.split("<", 1)
+    args = [a.strip() for a in args.rstrip("> ").split(",")]
+    at = {"wfTraceKernel": 0, "wfTraceLeanKernel": 2, "wfTraceLeanStreamKernel": 1, "wfTraceSwarmKernel": 0, "wfTraceGroupKernel": 2,
+          "wfGenerateKernel": 0, "wfShadeKernel": 1}.get(name.split("::")[-1])
+    return at is not None and at < len(args) and args[at] == "true"
+
+
 per = collections.defaultdict(lambda: collections.defaultdict(float))
 calls = collections.defaultdict(lambda: collections.defaultdict(int))
 meta = {}
@@ -28,7 +40,7 @@ for f in sorted(glob.glob(f"gpurun_out/pmc_{pmc_tag}_*/**/p_counter_collection.c
 out = {"note": note, "frames_profiled": frames, "fetch_size_factor": factor, "per_frame": {}}
 trace = collections.defaultdict(float)
 for k, c in sorted(per.items()):
-    counting = k.rstrip().endswith("true>")        # CNT instantiations: the un-timed counting renders of bench.py
+    counting = is_counting(k)                      # CNT instantiations: the un-timed counting renders of bench.py
     out["per_frame"][k] = {"dispatch": meta[k], "counting_render": counting, "launches_per_frame": max(calls[k].values()) / frames,
                            "counters": {n: v / frames for n, v in sorted(c.items())}}
     if "Trace" in k and not counting:
