@@ -480,7 +480,7 @@ def run(a, torch, dist, sharding, rank, local_rank, world, dev, rehearse):
                    "bvh_wide_depth": wl.info["wideDepth"], "arithmetic": a.mode, "parallelism": par,
                    "rays_per_frame": int(rays_all), "host_scene_build_s": round(wl.build_s, 2), "scene_upload_s": round(wl.upload_s, 2),
                    "device_scene_bytes": wl.tr.scene_device_bytes(),
-                   "schedule": {k: rinfo[k] for k in ("passes", "batch", "iterations", "compactFrom", "groupLanes", "frontierEntries", "contSlots", "coopFetch", "streamWords", "phasedTrips")}},
+                   "schedule": {k: rinfo[k] for k in ("passes", "batch", "iterations", "compactFrom", "groupLanes", "frontierEntries", "contSlots", "coopFetch", "streamWords", "phasedTrips", "handoverTrips")}},
         "roofline": wl.roofline(kernel_ms, launches, frame_ms, traffic, valu),
     }
     if not a.no_cpu_baseline and world == 1:

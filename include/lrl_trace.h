@@ -142,14 +142,16 @@ typedef struct LrlCounters {
  * ignore all but batchSlots / pollLag / debug.  lrl_create sets the defaults; lrl_set_tuning replaces them (and resets the
  * adaptive thresholds).  The library reads no environment variable on the render path. */
 #define LRL_TUNING_LIST_MAX 8u
+#define LRL_HANDOVER_AUTO 0xffffffffu
 typedef struct LrlTuning {
     uint32_t handoverEarly;      /* lean kernel: trips after which a ray still going is handed to the lanes-per-ray kernel, */
-    uint32_t handoverLate;       /*   first two segments / later segments (48 / 16; 0 = never hand over)                    */
+    uint32_t handoverLate;       /*   first two segments / later segments; 0 = never hand over; LRL_HANDOVER_AUTO (default) = */
+                                 /*   48 / 16, or 96 / 48 for scenes beyond the caches (more than 1 GiB of node records)       */
     uint32_t handoverListLen;    /* > 0: explicit thresholds per segment instead (the last one repeats)                     */
     uint32_t handoverList[LRL_TUNING_LIST_MAX];
     uint32_t adapt;              /* 1: thresholds ratchet up from the sampled work counters of earlier frames               */
-    uint32_t groupLanes;         /* lanes per handed-over ray: 8, 16, 32, or 64 (a wave per ray); 0 = 16, or 64 for scenes   */
-                                 /*   beyond the caches (more than 1 GiB of node records)                                    */
+    uint32_t groupLanes;         /* lanes per handed-over ray: 8, 16, 32, or 64 (a wave per ray); 0 = 16 (a wave per ray for */
+                                 /*   trees too deep for a group's frontier)                                                  */
     uint32_t contSlots;          /* hand-over records per launch; 0 = 262144 per 2^21 path slots of a launch                */
     uint32_t groupCapX;          /* frontier entries per ray = 256 x this (1, 2 or 4); 0 = by tree depth                    */
     uint32_t sparseFrom;         /* first segment traced with four-wave workgroups (5)                                      */
@@ -162,6 +164,7 @@ typedef struct LrlTuning {
     uint32_t coopFetch;          /* 1: the trace kernels fetch a 64-B record with four lanes (same records, same frame bit for bit).  A uniformly */
                                  /*   random gather out of more than ~2 GiB is bound by address translations per lane and gains 2.3x that way    */
                                  /*   (tools/probes/hbm_gather.hip); the rays of the measured scenes are more coherent and lose ~12 %.  0: off   */
+    uint32_t groupQuad;          /* 1: the lanes-per-ray hand-over kernel (groupLanes 16 / 32) puts four lanes to a frontier entry, one child each */
     uint32_t streamWords;        /* > 1: the lean trace kernel runs as waves that own this many 64-ray words of a launch and hand the next rays  */
     uint32_t refillMin;          /*   of their words to idle lanes whenever at least refillMin (16) lanes are idle; 0 / 1: one word per wave        */
     uint32_t phasedTrips;        /* triangle trips of the lean kernel: a trip on which many lanes hold a triangle runs the triangle block alone and the  */

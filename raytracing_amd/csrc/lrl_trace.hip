@@ -496,8 +496,8 @@ hipError_t noallocScratchFor(int device, void** out) {
 
 LrlTuning defaultTuning() {
     LrlTuning t{};
-    t.handoverEarly = 48; t.handoverLate = 16; t.handoverListLen = 0;
-    t.adapt = 1; t.groupLanes = 0; t.contSlots = 0; t.groupCapX = 0; t.sparseFrom = 5; t.compactFrom = -1; t.coopFetch = 0; t.streamWords = 0; t.refillMin = 16; t.phasedTrips = 0;
+    t.handoverEarly = LRL_HANDOVER_AUTO; t.handoverLate = LRL_HANDOVER_AUTO; t.handoverListLen = 0;
+    t.adapt = 1; t.groupLanes = 0; t.contSlots = 0; t.groupCapX = 0; t.sparseFrom = 5; t.compactFrom = -1; t.coopFetch = 0; t.groupQuad = 0; t.streamWords = 0; t.refillMin = 16; t.phasedTrips = 0;
     t.workLow = 12.0f; t.pollLag = 1; t.traceRef = 0; t.batchSlots = 0; t.debug = 0;
     return t;
 }
@@ -576,7 +576,7 @@ int lrl_set_tuning(LrlContext* c, const LrlTuning* t) {
     if (t->groupLanes != 0 && t->groupLanes != 8 && t->groupLanes != 16 && t->groupLanes != 32 && t->groupLanes != 64) return fail(c, LRL_ERR_INVALID_ARG, "groupLanes must be 0, 8, 16, 32 or 64");
     if ((t->groupCapX > 2 && t->groupCapX != 4) || t->compactFrom < -1 || !(t->workLow >= 0.0f)) return fail(c, LRL_ERR_INVALID_ARG, "groupCapX must be 0, 1, 2 or 4, compactFrom >= -1, workLow >= 0");
     if (t->contSlots > (1u << 22)) return fail(c, LRL_ERR_LIMIT, "contSlots > 2^22");
-    if (t->coopFetch > 1) return fail(c, LRL_ERR_INVALID_ARG, "coopFetch must be 0 or 1");
+    if (t->coopFetch > 1 || t->groupQuad > 1) return fail(c, LRL_ERR_INVALID_ARG, "coopFetch and groupQuad must be 0 or 1");
     if (t->phasedTrips > 2) return fail(c, LRL_ERR_INVALID_ARG, "phasedTrips must be 0 (by launch size), 1 (on) or 2 (off)");
     if (t->streamWords > 4096 || t->refillMin > 64) return fail(c, LRL_ERR_INVALID_ARG, "streamWords <= 4096, refillMin <= 64");
     c->tuning = *t;
@@ -1031,7 +1031,12 @@ static int renderWavefront(LrlContext* c, const LrlRenderParams* p, const KScene
     int rc = ensure(c, c->wfArena, full.total);
     if (rc) return rc;
     char* const base = static_cast<char*>(c->wfArena.p);
-    const uint32_t handoverEarly = tn.handoverEarly, handoverLate = tn.handoverLate;
+    // base thresholds of the hand-over: a scene in the caches is best off with early hand-overs (C2: a plateau around 48, 48, 32, 16, 16);
+    // beyond them a trip of the lean kernel and a round of the hand-over kernel both cost an HBM miss, and the lean kernel's ordered walk
+    // needs fewer of them per ray: later (C5 with 16 lanes per ray: 40.7 ms with 48 / 16, 35.3 with 64 / 32, 34.5 with 96 / 48, 35.3 with 128 / 64)
+    const bool beyondCachesThr = size_t(c->recNum) * 64 > (size_t(1) << 30);
+    const uint32_t handoverEarly = tn.handoverEarly != LRL_HANDOVER_AUTO ? tn.handoverEarly : beyondCachesThr ? 96u : 48u;
+    const uint32_t handoverLate = tn.handoverLate != LRL_HANDOVER_AUTO ? tn.handoverLate : beyondCachesThr ? 48u : 16u;
     // The hand-over pays for rays with much work left.  Where most rays are of middling length (Pool: flat tree of tall
     // boxes) the slots run out, or the rays that leave are nearly done and cost more to move than to finish, so the
     // threshold of an iteration follows what that iteration did in an earlier pass: doubled (x4 when far beyond
@@ -1040,15 +1045,16 @@ static int renderWavefront(LrlContext* c, const LrlRenderParams* p, const KScene
     // sample (160 ms a frame against 150 for any pinned state); a new scene starts from the defaults.  adapt = 0 pins them.
     // lanes per handed-over ray: groups of 16 when a group's share of the frontier holds the hand-over plus a depth-first
     // descent (lrl_lean.inc), else a wave per ray
-    // Beyond the caches (more than 1 GiB of node records) a round costs an HBM miss whatever it fetches, so a ray is better off with all
-    // 64 lanes and a 1024-entry frontier to itself (C5: 49.1 ms per frame with a wave per ray, 51.9 with 32 lanes, 60.0 with 16; C2, which
-    // sits in the caches: 1.43 / 1.38 / 1.32 ms)
+    // Round 2 measured 49.1 ms on C5 with a wave per ray against 60.0 with 16 lanes, and made the wave the default beyond the caches; with the
+    // later hand-over above and 512-entry frontiers (capX below) it is the other way round, because what bounds the rounds there is their latency
+    // and four rays a wave are four times the rays in flight: C5 44.3 ms with a wave per ray, 34.5 with 16 lanes (32 lanes: 35.0; 8: 34.3).
     const bool beyondCaches = size_t(c->recNum) * 64 > (size_t(1) << 30);
-    uint32_t swarmGroup = tn.groupLanes ? tn.groupLanes : beyondCaches ? 64u : 16u;
+    uint32_t swarmGroup = tn.groupLanes ? tn.groupLanes : 16u;
     // Four lanes to a record fetch (lrl_lean.inc).  A uniformly random gather out of 16 GiB runs 2.3x faster that way (address translations
     // per lane bound it: tools/probes/hbm_gather.hip), but the rays of C5 are not that incoherent: 54.2 against 48.5 ms per frame (every kernel
     // of the frame ~15 % slower: idle lanes fetch too, 8 shuffles + 16 swaps a trip).  Off unless asked for.
     const bool coop = tn.coopFetch == 1;
+    const bool groupQuad = tn.groupQuad == 1;      // lanes-per-ray kernel: four lanes to a frontier entry (the wave-per-ray kernel switches per round by itself)
     // Triangle trips (lrl_lean.inc, PH): -7 % on the Pool and -3 % on C5, +3-5 % on the coherent mirror rays of C2 / C4, and nothing the host knows
     // beforehand tells the two apart.  The frames are the same bit for bit either way, so the library times frames each way (events on the
     // caller's stream, read back without waiting) and keeps the faster for this scene and frame shape (two frames each way, alternating, after three that let the thresholds settle).  phasedTrips = 1 / 2 pins it.
@@ -1223,7 +1229,7 @@ static int renderWavefront(LrlContext* c, const LrlRenderParams* p, const KScene
                 const bool compact = compactFrom != 0 && iter >= compactFrom && iter < LRL_WF_MAX_ITERATIONS;
                 wf.listCount = listCounts + size_t(iter < LRL_WF_MAX_ITERATIONS ? iter : 0) * LRL_LIST_KINDS;
                 CRUMB_TRY(c, "trace (lean)", lrl_fast::wfLaunchTraceLean(k, wf, iter >= sparseFrom, compact, coop, phased, streamWords, refillMin, stream));
-                if (wf.handoverTrips) CRUMB_TRY(c, "trace (hand-over)", lrl_fast::wfLaunchTraceSwarm(k, wf, std::min(contSlots, c->swarmGrid[fi]), swarmGroup, coop, stream));
+                if (wf.handoverTrips) CRUMB_TRY(c, "trace (hand-over)", lrl_fast::wfLaunchTraceSwarm(k, wf, std::min(contSlots, c->swarmGrid[fi]), swarmGroup, coop, groupQuad, stream));
             }
             else CRUMB_TRY(c, "trace", fast ? lrl_fast::wfLaunchTrace(k, wf, stream) : lrl_parity::wfLaunchTrace(k, wf, stream));
             if (tb) HIP_TRY(c, hipEventRecord(tb, stream));

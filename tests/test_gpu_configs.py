@@ -52,9 +52,9 @@ def tie_adjusted_match(a, b, view):
 def test_c5_regime(tracer):
     """C5's regime at a size a test can afford: 5 x 5 replicated copies of the subdivided bunny (31 M triangles, 2 GB of node
     records: beyond every cache), tree built on the device, diffuse (incoherent) secondary rays, 1920 x 1080, 2 spp, depth 4.  At
-    this size the FAST pipeline switches on, by itself, the compaction of the late segments and the wave-per-ray hand-over kernel with
-    its 1024-entry frontier; both are asserted, not assumed, and the 16-lanes-per-ray kernel with 512-entry frontiers
-    (wfTraceGroupKernel<16, 2>) is run on the same frame."""
+    this size the FAST pipeline switches on, by itself, the compaction of the late segments, the later hand-over (96 / 48 trips) and
+    512-entry frontiers for the 16-lanes-per-ray hand-over kernel (wfTraceGroupKernel<16, 2>); all asserted, not assumed, and the
+    wave-per-ray kernel with its 1024-entry frontier (and its rounds of four lanes to an entry) is run on the same frame."""
     m = scenes.mesh_scene(subdivisions=2, builder="none", grid=5)
     W, H = 1920, 1080
     tr = m.camera(H)
@@ -69,15 +69,19 @@ def test_c5_regime(tracer):
     assert tracer.counters().raysPrimary == 2 * W * H and rays > 4 * W * H
     fast, fhits = tracer.render(max_depth=4, mode=abi.MODE_FAST, jitter=jit, diffuse=True)
     ri = tracer.last_render_info()
-    assert ri["compactFrom"] == 2 and ri["groupLanes"] == 64 and ri["frontierEntries"] == 1024 and ri["batch"] == 2, ri
-    # the 16-lanes-per-ray kernel with its 512-entry frontiers (what smaller deep trees get): the same frame bit for bit
+    assert ri["compactFrom"] == 2 and ri["groupLanes"] == 16 and ri["frontierEntries"] == 512 and ri["batch"] == 2, ri
+    assert ri["handoverTrips"][0] >= 96 and ri["handoverTrips"][3] >= 48, ri
+    # the wave-per-ray kernel with its 1024-entry frontier, the lanes-per-ray kernel with four lanes to an entry, and the early
+    # hand-over of scenes in the caches: the same frame bit for bit
     base = tracer.get_tuning()
     try:
-        tracer.set_tuning(groupLanes=16)
-        fast16, fhits16 = tracer.render(max_depth=4, mode=abi.MODE_FAST, jitter=jit, diffuse=True)
-        ri16 = tracer.last_render_info()
-        assert ri16["groupLanes"] == 16 and ri16["frontierEntries"] == 512, ri16
-        assert np.array_equal(fast16.view(np.uint32), fast.view(np.uint32)) and np.array_equal(fhits16, fhits)
+        for kw, lanes, entries in (({"groupLanes": 64}, 64, 1024), ({"groupQuad": 1}, 16, 512), ({"groupLanes": 32, "groupCapX": 2, "handoverEarly": 48, "handoverLate": 16}, 32, 512)):
+            tracer.set_tuning(base)
+            tracer.set_tuning(**kw)
+            fast2, fhits2 = tracer.render(max_depth=4, mode=abi.MODE_FAST, jitter=jit, diffuse=True)
+            ri2 = tracer.last_render_info()
+            assert ri2["groupLanes"] == lanes and ri2["frontierEntries"] == entries, ri2
+            assert np.array_equal(fast2.view(np.uint32), fast.view(np.uint32)) and np.array_equal(fhits2, fhits), kw
     finally:
         tracer.set_tuning(base)
     view = m.scene_view()

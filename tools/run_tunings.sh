@@ -10,6 +10,6 @@ for t in "$@"; do
 import json,sys
 j=json.loads(open(sys.argv[2]).read().strip().splitlines()[-1])
 r=j["roofline"]
-print(f'{sys.argv[1]:40s} ms/step {j["ms_per_step"]:9.3f}  Mrays/s {j["value"]:9.1f}  trace ms {r["kernel_ms"]:9.3f}  launches {r["launches_per_frame"]:5d}  sched {j["config"]["schedule"]}')
+print(f'{sys.argv[1]:40s} ms/step {j["ms_per_step"]:9.3f}  Mrays/s {j["value"]:9.1f}  trace ms {r["kernel_ms"]:9.3f}  launches {r["launches_per_frame"]:5d}  thr {j["config"]["schedule"].get("handoverTrips", [])[:5]} lanes {j["config"]["schedule"]["groupLanes"]} slots {j["config"]["schedule"]["contSlots"]} ph {j["config"]["schedule"].get("phasedTrips")}')
 PY
 done
