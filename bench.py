@@ -22,9 +22,11 @@ Roofline (two records in the one JSON line):
                = traffic / kernel time / 8 TB/s; `work` = SURVEY 8d's algorithmic bytes (reference-order visit counts).  Workloads
                without a PMC record of their own (other scenes, --tuning) report `bound` = "l1" with the gather figure.
   roofline_c5  SURVEY 8d's C5, the configuration the memory roofline is judged on (100.5 M triangles, device-built tree, diffuse
-               bounces, 16 spp; 22 GB of scene, far beyond the caches): `achieved` = algorithmic bytes / trace-kernel time against
-               the 8 TB/s HBM peak, with PMC traffic, hbm_frac, the HBM line-request rate beside what tools/probes/hbm_gather.hip
-               measured this chip to give such a stream, and valu_issue.  N = 1 default runs only (--no-c5 skips it).
+               bounces, 16 spp; 22 GB of scene, far beyond the caches): `achieved` = the HBM traffic of the trace kernels (PMC passes of
+               the same kernels on the same workload, profiles/r02_traffic_c5.json) / this run's trace-kernel time against the 8 TB/s
+               HBM peak; `algorithmic_frac` = SURVEY 8d's algorithmic bytes over the same time (the caches serve part of them, so it
+               can pass 1); the HBM line-request rate beside what tools/probes/hbm_gather.hip measured this chip to give such a
+               stream, and valu_issue.  N = 1 default runs only (--no-c5 skips it).
 
 N > 1 (one rank per GPU; `python bench.py --gpus N` starts the ranks itself through torch.distributed.run when it is not already
 under one): the scene is replicated.
@@ -282,9 +284,15 @@ class Workload:
                 r.update({k: l1[k] for k in ("achieved", "peak", "unit", "frac", "fetched_bytes_per_frame")})
                 r["l1_note"] = l1["note"]
         else:
-            ach = self.alg_bytes / (kernel_ms * 1e-3) / 1e9
+            # beyond the caches: the bytes that did cross the HBM interface (PMC passes of the same kernels on the same workload: FETCH_SIZE x 2 +
+            # WRITE_SIZE, a count that barely depends on the run) over this run's kernel time; without a PMC record, SURVEY 8d's algorithmic
+            # bytes (the caches serve part of those, so that figure can pass 1)
+            alg = self.alg_bytes / (kernel_ms * 1e-3) / 1e9
+            ach = traffic / (kernel_ms * 1e-3) / 1e9 if traffic else alg
             r.update({"bound": "hbm", "level": "HBM: the working set is far beyond the 256 MiB Infinity Cache" if not resident else "Infinity Cache resident",
+                      "basis": "HBM traffic of the trace kernels measured by PMC (profiles/)" if traffic else "algorithmic bytes (SURVEY 8d)",
                       "achieved": round(ach, 2), "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBPS, 5),
+                      "algorithmic_frac": round(alg / HBM_PEAK_GBPS, 5),
                       "fetched_bytes_per_frame": int(self.fetch_bytes) if self.fetch_bytes else None})
         if traffic:
             # every L2 miss is one 128-B request (TCC_EA0_RDREQ_128B = TCC_EA0_RDREQ in the PMC passes)

@@ -146,7 +146,8 @@ typedef struct LrlCounters {
 typedef struct LrlTuning {
     uint32_t handoverEarly;      /* lean kernel: trips after which a ray still going is handed to the lanes-per-ray kernel, */
     uint32_t handoverLate;       /*   first two segments / later segments; 0 = never hand over; LRL_HANDOVER_AUTO (default) = */
-                                 /*   48 / 16, or 96 / 48 for scenes beyond the caches (more than 1 GiB of node records)       */
+                                 /*   48 / 16; 64 / 32 for launches of 2^23 path slots and more (batches of samples, 4K);       */
+                                 /*   96 / 48 for scenes beyond the caches (more than 1 GiB of node records)                    */
     uint32_t handoverListLen;    /* > 0: explicit thresholds per segment instead (the last one repeats)                     */
     uint32_t handoverList[LRL_TUNING_LIST_MAX];
     uint32_t adapt;              /* 1: thresholds ratchet up from the sampled work counters of earlier frames               */

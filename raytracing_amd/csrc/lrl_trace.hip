@@ -101,6 +101,7 @@ struct LrlContext {
     uint32_t contIters = 0;             // words of contHost in flight / ready
     std::vector<LrlTrans> transUploaded;   // what transDev holds (per-sample cameras of the last render)
     std::vector<uint32_t> handoverThr;  // per iteration index; empty until first use
+    uint32_t handoverRegime = 0;        // what the base thresholds were chosen for: 0 a sample in the caches, 1 a large launch, 2 a scene beyond the caches
     std::vector<uint32_t> swarmGrid;    // waves launched for the handed-over rays of that iteration (a grid-stride kernel)
     hipEvent_t evIter[4] = {nullptr, nullptr, nullptr, nullptr};
     bool hasTransmission = false;       // some material has t != 0: refraction stacks are needed
@@ -1034,9 +1035,13 @@ static int renderWavefront(LrlContext* c, const LrlRenderParams* p, const KScene
     // base thresholds of the hand-over: a scene in the caches is best off with early hand-overs (C2: a plateau around 48, 48, 32, 16, 16);
     // beyond them a trip of the lean kernel and a round of the hand-over kernel both cost an HBM miss, and the lean kernel's ordered walk
     // needs fewer of them per ray: later (C5 with 16 lanes per ray: 40.7 ms with 48 / 16, 35.3 with 64 / 32, 34.5 with 96 / 48, 35.3 with 128 / 64)
-    const bool beyondCachesThr = size_t(c->recNum) * 64 > (size_t(1) << 30);
-    const uint32_t handoverEarly = tn.handoverEarly != LRL_HANDOVER_AUTO ? tn.handoverEarly : beyondCachesThr ? 96u : 48u;
-    const uint32_t handoverLate = tn.handoverLate != LRL_HANDOVER_AUTO ? tn.handoverLate : beyondCachesThr ? 48u : 16u;
+    // A launch of many waves per slot (batches of samples, 4K frames) is bound less by its chains than a 1080p sample: in between (C4, 2^25
+    // path slots a launch: 865 ms with 48 / 16, 797 with 64 / 32, 807 with 96 / 48, 844 without hand-over).
+    const bool beyondCachesThr = size_t(c->recNum) * 64 > (size_t(1) << 30), bigLaunch = Ppix64 * batch >= (1ull << 23);
+    const uint32_t regime = beyondCachesThr ? 2u : bigLaunch ? 1u : 0u;
+    if (c->handoverRegime != regime) { c->handoverRegime = regime; c->handoverThr.clear(); c->feedbackTick = 0; c->contIters = 0; }
+    const uint32_t handoverEarly = tn.handoverEarly != LRL_HANDOVER_AUTO ? tn.handoverEarly : regime == 2 ? 96u : regime == 1 ? 64u : 48u;
+    const uint32_t handoverLate = tn.handoverLate != LRL_HANDOVER_AUTO ? tn.handoverLate : regime == 2 ? 48u : regime == 1 ? 32u : 16u;
     // The hand-over pays for rays with much work left.  Where most rays are of middling length (Pool: flat tree of tall
     // boxes) the slots run out, or the rays that leave are nearly done and cost more to move than to finish, so the
     // threshold of an iteration follows what that iteration did in an earlier pass: doubled (x4 when far beyond
