@@ -31,7 +31,7 @@ Roofline (two records in the one JSON line):
 N > 1 (one rank per GPU; `python bench.py --gpus N` starts the ranks itself through torch.distributed.run when it is not already
 under one): the scene is replicated.
   --scaling weak   (default for c1/c2/c3/c5) every rank renders the whole frame for its own sample indices of an N x spp jitter table
-                   (per-GPU work fixed); the partial means are summed with one RCCL all-reduce per step inside the timed region, which
+                   (per-GPU work fixed); the partial means are summed onto rank 0 with one RCCL reduce per step inside the timed region, which
                    overlaps the rendering of the next frame (two image buffers, stream-level waits only).
   --scaling strong (default for c4: ONE 3840x2160 x 256 spp frame of the C2 scene) every rank renders its interleaved 16-row stripes
                    (LrlRenderParams.rowInterleave, one call), one RCCL all-gather per frame inside the timed region + the un-interleave.
@@ -380,13 +380,14 @@ def run(a, torch, dist, sharding, rank, local_rank, world, dev, rehearse):
     # pool streams of its own), with two processes on one GPU.  RCCL has no such thread and no staging.
     overlap = world > 1 and scaling == "weak" and not a.no_overlap and not rehearse
 
+    # the frame is needed in one place (the reference shows it in one window): a reduce to rank 0 moves half the bytes of an all-reduce
     def all_reduce_(t):
         if rehearse:
             h = t.cpu()
-            dist.all_reduce(h, op=dist.ReduceOp.SUM)
+            dist.reduce(h, dst=0, op=dist.ReduceOp.SUM)
             t.copy_(h)
         else:
-            dist.all_reduce(t, op=dist.ReduceOp.SUM)
+            dist.reduce(t, dst=0, op=dist.ReduceOp.SUM)
 
     def all_gather_(full, mine):
         if rehearse:
@@ -420,7 +421,7 @@ def run(a, torch, dist, sharding, rank, local_rank, world, dev, rehearse):
                 if works[1 - b] is not None:
                     works[1 - b].wait()
                     works[1 - b] = None
-                works[b] = dist.all_reduce(outs[b], op=dist.ReduceOp.SUM, async_op=True)
+                works[b] = dist.reduce(outs[b], dst=0, op=dist.ReduceOp.SUM, async_op=True)
         counter[0] += 1
         if rehearse:
             print(f"[rehearsal] rank {rank}: step {counter[0]} queued", file=sys.stderr, flush=True)
@@ -470,13 +471,14 @@ def run(a, torch, dist, sharding, rank, local_rank, world, dev, rehearse):
     value = rays_all * steps / elapsed / 1e6
     frame_ms = frame_ms_total / max(frames, 1)
     traffic = valu = None
-    if world == 1 and a.workload == "c2" and not a.tuning:
+    # (weak scaling: rank 0's frame is the one-GPU frame with its own sample index, the same kernels over the same scene)
+    if (world == 1 or scaling == "weak") and a.workload == "c2" and not a.tuning:
         traffic, valu = load_traffic("r02_traffic.json", {"workload_triangles": int(wl.view.num.triangleNum), "mode": a.mode, "builder": wl.builder,
                                                     "width": W, "height": H, "spp": wl.spp, "depth": wl.depth, "diffuse": wl.diffuse})
     if world == 1 and a.workload == "c5" and not a.tuning and not (a.grid or a.spp or a.depth or a.width or a.builder or a.diffuse):
         traffic, valu = load_traffic("r02_traffic_c5.json", {"workload_triangles": int(wl.view.num.triangleNum), "spp": wl.spp, "depth": wl.depth})
     if world > 1:
-        par = (f"replicated scene, {wl.spp} sample indices per GPU, RCCL all-reduce of the image" + (" overlapping the next frame" if overlap else "")
+        par = (f"replicated scene, {wl.spp} sample indices per GPU, RCCL reduce of the image onto rank 0" + (" overlapping the next frame" if overlap else "")
                if scaling == "weak" else "replicated scene, interleaved 16-row stripes per GPU, RCCL all-gather of the frame")
     else:
         par = "1 GPU"
