@@ -89,6 +89,7 @@ struct LrlContext {
         bool choice = false;
         hipEvent_t ev[8] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};      // start, end of the four timed frames
     } phasedTrial;
+    hipEvent_t evSceneReady = nullptr;  // recorded on the context's stream when a render starts on another one, which waits for it
     hipEvent_t evLastRender = nullptr;  // recorded behind every render: a render on another stream waits for it (the arena is shared)
     hipStream_t lastRenderStream = nullptr;
     bool renderedOnce = false;
@@ -191,6 +192,14 @@ int validateBVH(LrlContext* c, const LrlSceneView* s, uint32_t& depthOut) {
     }
     depthOut = depth;
     if (depth + 1 > LRL_MAX_BVH_DEPTH) return fail(c, LRL_ERR_BVH_DEPTH, "BVH deeper than LRL_MAX_BVH_DEPTH");
+    return LRL_OK;
+}
+
+// A call that changes the scene works on the context's stream (or copies after waiting for it); the last render may have run on a stream of
+// the caller's (lrl_render_async) and may still be reading what the call is about to change: the context's stream waits for it, on the device.
+// The other direction is renderImpl's: a render on a caller's stream waits for what the context's stream still has queued.
+int orderAfterRenders(LrlContext* c) {
+    if (c->renderedOnce && c->lastRenderStream != c->stream) HIP_TRY(c, hipStreamWaitEvent(c->stream, c->evLastRender, 0));
     return LRL_OK;
 }
 
@@ -549,7 +558,8 @@ int lrl_create(int device, LrlContext** out) {
               hipHostMalloc(reinterpret_cast<void**>(&c->contHost), LRL_FEEDBACK_ITERS * 32, hipHostMallocDefault) == hipSuccess &&
               hipHostGetDevicePointer(reinterpret_cast<void**>(&c->contHostDev), c->contHost, 0) == hipSuccess &&
               hipEventCreateWithFlags(&c->evCont, hipEventDisableTiming) == hipSuccess &&
-              hipEventCreateWithFlags(&c->evLastRender, hipEventDisableTiming) == hipSuccess;
+              hipEventCreateWithFlags(&c->evLastRender, hipEventDisableTiming) == hipSuccess &&
+              hipEventCreateWithFlags(&c->evSceneReady, hipEventDisableTiming) == hipSuccess;
     for (hipEvent_t& e : c->evIter) ok = ok && hipEventCreateWithFlags(&e, hipEventDisableTiming) == hipSuccess;
     for (hipEvent_t& e : c->phasedTrial.ev) ok = ok && hipEventCreate(&e) == hipSuccess;
     ok = ok && noallocScratchFor(device, &c->noallocScratch) == hipSuccess;
@@ -600,6 +610,7 @@ int lrl_destroy(LrlContext* c) {
     if (c->contHost) (void)hipHostFree(c->contHost);
     if (c->evCont) (void)hipEventDestroy(c->evCont);
     if (c->evLastRender) (void)hipEventDestroy(c->evLastRender);
+    if (c->evSceneReady) (void)hipEventDestroy(c->evSceneReady);
     for (hipEvent_t e : c->evIter) if (e) (void)hipEventDestroy(e);
     for (hipEvent_t e : c->phasedTrial.ev) if (e) (void)hipEventDestroy(e);
     if (c->evStart) (void)hipEventDestroy(c->evStart);
@@ -666,6 +677,8 @@ int lrl_scene_upload(LrlContext* c, const LrlSceneView* s) {
     if (c) { c->handoverThr.clear(); c->feedbackTick = 0; c->contIters = 0; c->phasedTrial.state = 0; c->phasedTrial.signature = 0; }      // the hand-over thresholds start again with a new scene (feedback still in flight is the old scene's: dropped)
     if (!c || !s) return LRL_ERR_INVALID_ARG;
     HIP_TRY(c, hipSetDevice(c->device));
+    if (int rc0 = orderAfterRenders(c)) return rc0;
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
     const LrlGeometryNum& g = s->num;
     if (g.triangleNum && !s->trianglesOrigin == !s->trianglesGPU)
         return fail(c, LRL_ERR_INVALID_ARG, "exactly one of trianglesOrigin / trianglesGPU must be given");
@@ -790,6 +803,7 @@ int lrl_scene_update_triangles(LrlContext* c, uint32_t first, uint32_t count, co
     if (!c->haveScene) return fail(c, LRL_ERR_NO_SCENE, "no scene uploaded");
     if (uint64_t(first) + count > c->num.triangleNum) return fail(c, LRL_ERR_INVALID_ARG, "triangle range out of bounds");
     HIP_TRY(c, hipSetDevice(c->device));
+    if (int rc0 = orderAfterRenders(c)) return rc0;
     return runTrianglePre(c, first, count, tris);
 }
 
@@ -801,6 +815,7 @@ int lrl_scene_update_triangles_noalloc(LrlContext* c, uint32_t first, uint32_t c
     if (!count) return LRL_OK;
     if (!c->noallocScratch) return fail(c, LRL_ERR_DEVICE, "the static staging area was not resolved for this device");
     HIP_TRY(c, hipSetDevice(c->device));
+    if (int rc0 = orderAfterRenders(c)) return rc0;      // (a stream-level wait: allocates nothing)
     // materials: looked up only; a new one would grow the table (host and device allocations)
     for (uint32_t i = 0; i < count; ++i) {
         ColorKey k;
@@ -841,6 +856,7 @@ int lrl_scene_update_primitives(LrlContext* c, uint32_t kind, uint32_t first, ui
     if (uint64_t(first) + count > have) return fail(c, LRL_ERR_INVALID_ARG, "primitive range out of bounds");
     if (!count) return LRL_OK;
     HIP_TRY(c, hipSetDevice(c->device));
+    if (int rc0 = orderAfterRenders(c)) return rc0;
     HIP_TRY(c, hipStreamSynchronize(c->stream));      // frames in flight read these records
     HIP_TRY(c, hipMemcpy(static_cast<char*>(buf->p) + size_t(first) * size, records, size_t(count) * size, hipMemcpyHostToDevice));
     if (kind == LRL_PRIM_LIGHT) return LRL_OK;
@@ -880,6 +896,7 @@ int lrl_scene_update_bvh(LrlContext* c, const LrlBVHNode* bvh, uint32_t bvhNodeN
     uint32_t depth = 0, recCount = 1;
     int rc = validateBVH(c, &v, depth);
     if (rc) return rc;
+    if ((rc = orderAfterRenders(c))) return rc;
     HIP_TRY(c, hipStreamSynchronize(c->stream));      // frames in flight walk the old tree
     c->haveScene = false;                             // (a failed upload leaves no half-written tree in use)
     if ((rc = uploadCallerTree(c, &v, recCount))) return rc;
@@ -1308,6 +1325,11 @@ static int renderImpl(LrlContext* c, const LrlRenderParams* p, float* rgbaDev, u
     // one arena, one set of per-sample cameras and of polled words per context: a render on another stream than the last one
     // waits (on the device) for that one to end
     if (c->renderedOnce && stream != c->lastRenderStream) CRUMB_TRY(c, "hipStreamWaitEvent(last render)", hipStreamWaitEvent(stream, c->evLastRender, 0));
+    // scene changes still queued on the context's stream (lrl_water_step, lrl_scene_rebuild_bvh return before their kernels end)
+    if (stream != c->stream) {
+        CRUMB_TRY(c, "hipEventRecord(scene ready)", hipEventRecord(c->evSceneReady, c->stream));
+        CRUMB_TRY(c, "hipStreamWaitEvent(scene ready)", hipStreamWaitEvent(stream, c->evSceneReady, 0));
+    }
     // the per-sample cameras go to the device only when they changed: an unchanged camera costs no copy and no host wait,
     // so consecutive frames queue back to back
     if (c->transUploaded.size() != tr.size() || std::memcmp(c->transUploaded.data(), tr.data(), tr.size() * sizeof(LrlTrans)) != 0) {
@@ -1545,6 +1567,7 @@ int lrl_scene_rebuild_bvh(LrlContext* c) {
     if (!c->haveScene) return fail(c, LRL_ERR_NO_SCENE, "no scene uploaded");
     if (!c->deviceBuilt) return fail(c, LRL_ERR_INVALID_ARG, "the tree came from the caller (LrlSceneView.bvh): it is never rebuilt here");
     HIP_TRY(c, hipSetDevice(c->device));
+    if (int rc0 = orderAfterRenders(c)) return rc0;
     uint32_t recCount = 0, depth = 0;
     const int rc = runDeviceBuild(c, c->primTotal, recCount, depth);
     if (rc) return rc;
@@ -1578,6 +1601,7 @@ int lrl_water_step(LrlContext* c, uint32_t substeps) {
     if (!c) return LRL_ERR_INVALID_ARG;
     if (!c->waterGX) return fail(c, LRL_ERR_NO_SCENE, "lrl_water_init first");
     HIP_TRY(c, hipSetDevice(c->device));
+    if (int rc0 = orderAfterRenders(c)) return rc0;
     const uint32_t count = 2u * (c->waterGX - 1) * (c->waterGY - 1);
     HIP_TRY(c, lrl_launch_water_run(static_cast<float4*>(c->waterPoints.p), c->waterGX, c->waterGY, c->waterK, c->waterDt, substeps,
                                     static_cast<LrlTriangle*>(c->waterTris.p), c->stream));

@@ -980,3 +980,49 @@ def test_moving_spheres_and_lights_like_movement_run(tracer):
         assert np.array_equal(tracer.render(max_depth=6)[1], par[1])          # a refused update leaves the scene as it was
     finally:
         dev.close(); fresh.close()
+
+
+def test_scene_changes_and_renders_on_a_callers_stream_are_ordered(pool_model):
+    """lrl_water_step only queues its kernels on the context's stream, and lrl_render_async may run on a stream of the caller's: a render
+    must see the water step queued before it, and the next water step (or triangle update) must not overwrite triangles the render in
+    flight still reads.  Frame loop water step -> render on a foreign stream, nothing waited for in between, against the same loop with
+    blocking renders on the context's own stream: the same frames bit for bit, with the library's tree rebuilt every frame."""
+    import torch
+    from raytracing_amd import tracer as T
+    g = np.load(os.path.join(GOLDEN, "pool_water_steps.npz"))
+    gx, gy, k, dt = int(g["gx"]), int(g["gy"]), float(g["k"]), float(g["dt"])
+    nw = 2 * (gx - 1) * (gy - 1)
+    gP = load_golden("pool_viewA_160")
+    W = H = 160
+    tris = pool_model.arrays()["triangles"]
+    w0 = scenes.pool_water_points(pool_model)
+    view = pool_model.scene_view()
+    view.bvh = None; view.bvhNodeNum = 0
+    frames = {}
+    for mode in ("blocking", "foreign stream"):
+        t = T.Tracer(0)
+        try:
+            t.scene_upload(view)
+            t.water_init(gx, gy, k, dt, w0, 0, tris[:nw])
+            t.set_camera(gP["trans"], W, H)
+            t.set_decay_origin((0, 0, 0, 1))
+            outs = [torch.zeros((H, W, 4), dtype=torch.float32, device="cuda:0") for _ in range(4)]
+            stream = torch.cuda.Stream(device="cuda:0")
+            got = []
+            for i in range(4):
+                t.water_step(25)
+                t.rebuild_bvh()
+                if mode == "blocking":
+                    got.append(t.render(max_depth=8, variant=abi.VARIANT_POOL, mode=abi.MODE_FAST, want_hits=False)[0])
+                else:
+                    t.render_device(outs[i].data_ptr(), stream=stream.cuda_stream, max_depth=8, variant=abi.VARIANT_POOL, mode=abi.MODE_FAST)
+            if mode != "blocking":
+                stream.synchronize()
+                t.sync()
+                got = [o.cpu().numpy() for o in outs]
+            frames[mode] = got
+        finally:
+            t.close()
+    for i in range(4):
+        assert np.array_equal(frames["blocking"][i].view(np.uint32), frames["foreign stream"][i].view(np.uint32)), i
+    assert not np.array_equal(frames["blocking"][0], frames["blocking"][3])      # the water did move
