@@ -5,7 +5,7 @@ import os
 import numpy as np
 import pytest
 
-from conftest import GOLDEN
+from conftest import GOLDEN, REPO
 from raytracing_amd import abi, host, scenes
 
 
@@ -149,3 +149,21 @@ def test_coincident_centres_terminate():
     m.add_triangles(t)
     m.data_init()
     check_invariants(m)
+
+
+def test_transform_operate_cpp():
+    """lrl::Transform::operate, the interactive camera (SURVEY 8f rank 3): the reference's key / mouse maths is not recoverable, this
+    is the library's own; tests/cpp/transform_operate.cpp pins its properties (camera-frame translation, decaying dolly, drag angle =
+    |drag| / depth, orthonormal rotation after hundreds of increments, dirty flags, Trans record, jitter shear)."""
+    import shutil
+    import subprocess
+    import tempfile
+    cxx = shutil.which("g++")
+    assert cxx, "g++ is part of the image"
+    with tempfile.TemporaryDirectory() as td:
+        exe = os.path.join(td, "transform_operate")
+        r = subprocess.run([cxx, "-std=c++17", "-O1", "-Wall", "-I" + os.path.join(REPO, "raytracing_amd", "host"), "-I" + os.path.join(REPO, "include"),
+                            "-o", exe, os.path.join(REPO, "tests", "cpp", "transform_operate.cpp")], capture_output=True, text=True)
+        assert r.returncode == 0, r.stderr
+        r = subprocess.run([exe], capture_output=True, text=True, timeout=60)
+        assert r.returncode == 0 and "ok" in r.stdout, r.stdout + r.stderr
