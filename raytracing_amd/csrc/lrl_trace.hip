@@ -62,10 +62,16 @@ struct LrlContext {
     DevBuf waterPoints, waterTris, waterMat;   // Pool water simulation (lrl_water_*)
     uint32_t waterGX = 0, waterGY = 0, waterFirst = 0;
     float waterK = 0, waterDt = 0;
-    DevBuf nodes, nodes32, triHot, triCold, materials, spheres, circles, cylinders, cones, lights, tex, cube, triStage, matStage;
+    DevBuf nodes, nodes32, nodes32Loose, triHot, triCold, materials, spheres, circles, cylinders, cones, lights, tex, cube, triStage, matStage;
     uint32_t texW = 0, texH = 0, texL = 0, cubeSize = 0;
     std::vector<LrlColor> materialTable;
     std::unordered_map<ColorKey, uint32_t, ColorHash> materialIndex;
+    // callers' trees: the primitives' own boxes by BVH geometry code (six floats each, min > max: not known), kept current by the
+    // update calls; the four-wide tree bounds a primitive that the caller parked in an inner node by them (buildNode4)
+    std::vector<float> ownBox[7];
+    uint32_t parkedTight = 0;     // parked primitives that nodes32 bounds by their own boxes
+    bool haveLoose = false;       // nodes32Loose holds the same four-wide tree with the caller's boxes only
+    bool looseInUse = false;      // primitives changed under the caller's tree since it came: its boxes alone are the contract (ownBoxesStale)
 
     // frame
     LrlTrans trans{};
@@ -205,7 +211,7 @@ int orderAfterRenders(LrlContext* c) {
 
 void fillKScene(const LrlContext* c, KScene& k) {
     k.recs = static_cast<const float4*>(c->nodes.p);
-    k.node4 = static_cast<const uint4*>(c->nodes32.p);
+    k.node4 = static_cast<const uint4*>(c->looseInUse ? c->nodes32Loose.p : c->nodes32.p);
     k.triHot = static_cast<const float4*>(c->triHot.p);
     k.triCold = static_cast<const LrlTriCold*>(c->triCold.p);
     k.materials = static_cast<const LrlColor*>(c->materials.p);
@@ -231,7 +237,7 @@ std::vector<uchar4> bgrToRgbx(const uint8_t* bgr, size_t texels) {
 
 // Four-wide, compressed repack of the caller's binary tree for the FAST lean kernel (lrl_lean.inc).  A node's items are
 // its parked primitive and its children; an inner child is replaced by ITS items while the node stays within four (largest
-// box first).  The node of binary inner node b is stored at b's record index (recOf[b], the index `recs` uses), so refs mean
+// box first).  A parked primitive is bounded by its own box where that is known (ownBox; nullptr: by its node's, as the reference tests it).  The node of binary inner node b is stored at b's record index (recOf[b], the index `recs` uses), so refs mean
 // the same in both trees and a ray can change from one to the other at any ref; record indices of binary nodes that were
 // merged into their parent stay unused.  64 B per node:
 //   {origin.x, origin.y, origin.z, unit.x}                       origin = min corner of the items' boxes; unit = per-axis
@@ -239,18 +245,38 @@ std::vector<uchar4> bgrToRgbx(const uint8_t* bgr, size_t texels) {
 //   {lo.x of items 0..3 (one byte each), lo.y, lo.z, hi.x}       box = origin + byte * unit, rounded outwards
 //   {hi.y, hi.z, ref0, ref1}  {ref2, ref3, unit.y, unit.z}       ref: record index, LRL_REF_LEAF | primitive, or LRL_REF_EMPTY4 with an
 //                                                                inverted box (lo 255, hi 0) for an empty slot
-std::vector<uint4> buildNode4(const LrlSceneView* s, const std::vector<uint32_t>& recOf, uint32_t recCount, uint32_t& depthOut) {
+std::vector<uint4> buildNode4(const LrlSceneView* s, const std::vector<float>* ownBox, const std::vector<uint32_t>& recOf, uint32_t recCount, uint32_t& depthOut, size_t& tightened) {
     const LrlBVHNode* bvh = s->bvh;
-    struct Item { bool inner; uint32_t ref; uint32_t boxOf; };      // inner: binary node index; else primitive bits; boxOf: binary node whose box bounds it
+    struct Item { bool inner; uint32_t ref; float lo[3], hi[3]; };      // inner: binary node index; else primitive bits
     auto primOf = [&](const LrlBVHNode& n) { return (uint32_t(n.geometry) << LRL_PRIM_TYPE_SHIFT) | (n.geometryNum & LRL_PRIM_INDEX_MASK); };
+    auto boxed = [&](bool inner, uint32_t ref, uint32_t boxOf) {
+        Item it{inner, ref, {0, 0, 0}, {0, 0, 0}};
+        for (int a = 0; a < 3; ++a) { it.lo[a] = bvh[boxOf].bound.min[a]; it.hi[a] = bvh[boxOf].bound.max[a]; }
+        return it;
+    };
+    // A primitive parked in an inner node: the reference tests it whenever the ray enters that node's box, which spans the
+    // whole subtree.  Its own box says the same for every ray that can hit it and turns most of the others away, as long as
+    // it lies within the node's box (a tree where it does not keeps the node's box: then the node's box decides, as in the reference).
+    auto parked = [&](const LrlBVHNode& n, uint32_t b) {
+        Item it = boxed(false, primOf(n), b);
+        if (!ownBox || n.geometry >= 7) return it;
+        const std::vector<float>& own = ownBox[n.geometry];
+        const size_t at = size_t(n.geometryNum) * 6;
+        if (at + 6 > own.size()) return it;
+        const float* q = &own[at];
+        for (int a = 0; a < 3; ++a) if (!(q[a] <= q[3 + a]) || q[a] < it.lo[a] || q[3 + a] > it.hi[a]) return it;
+        for (int a = 0; a < 3; ++a) { it.lo[a] = q[a]; it.hi[a] = q[3 + a]; }
+        it.inner = true;      // (for the count below; the caller clears it)
+        return it;
+    };
     auto asItem = [&](uint32_t cnode, Item* out, int& k) {
-        if (bvh[cnode].bound.leftChild) out[k++] = {true, cnode, cnode};
-        else if (bvh[cnode].geometry) out[k++] = {false, primOf(bvh[cnode]), cnode};
+        if (bvh[cnode].bound.leftChild) out[k++] = boxed(true, cnode, cnode);
+        else if (bvh[cnode].geometry) out[k++] = boxed(false, primOf(bvh[cnode]), cnode);
     };
     auto contents = [&](uint32_t b, Item* out) -> int {
         const LrlBVHNode& n = bvh[b];
         int k = 0;
-        if (n.geometry) out[k++] = {false, primOf(n), b};
+        if (n.geometry) { out[k] = parked(n, b); out[k++].inner = false; }
         if (n.bound.leftChild) {
             asItem(b + 1, out, k);
             if (n.bound.rightChild) asItem(uint32_t(n.bound.rightChild), out, k);
@@ -297,8 +323,8 @@ std::vector<uint4> buildNode4(const LrlSceneView* s, const std::vector<uint32_t>
         double lo[3] = {1e300, 1e300, 1e300}, hi[3] = {-1e300, -1e300, -1e300};
         for (int i = 0; i < n; ++i)
             for (int a = 0; a < 3; ++a) {
-                lo[a] = std::min(lo[a], double(bvh[items[i].boxOf].bound.min[a]));
-                hi[a] = std::max(hi[a], double(bvh[items[i].boxOf].bound.max[a]));
+                lo[a] = std::min(lo[a], double(items[i].lo[a]));
+                hi[a] = std::max(hi[a], double(items[i].hi[a]));
             }
         float origin[3] = {0, 0, 0};
         uint32_t expo[3] = {127, 127, 127};
@@ -318,10 +344,9 @@ std::vector<uint4> buildNode4(const LrlSceneView* s, const std::vector<uint32_t>
         for (int i = n; i < 4; ++i)
             for (int a = 0; a < 3; ++a) bytes[a] |= LRL_EMPTY4_LO << (8 * i);      // empty slots: inverted boxes
         for (int i = 0; i < n; ++i) {
-            const LrlBound& bb = bvh[items[i].boxOf].bound;
             for (int a = 0; a < 3; ++a) {
-                const double ql = std::floor((double(bb.min[a]) - double(origin[a])) / unit[a]);
-                const double qh = std::ceil((double(bb.max[a]) - double(origin[a])) / unit[a]);
+                const double ql = std::floor((double(items[i].lo[a]) - double(origin[a])) / unit[a]);
+                const double qh = std::ceil((double(items[i].hi[a]) - double(origin[a])) / unit[a]);
                 bytes[a] |= uint32_t(std::min(255.0, std::max(0.0, ql))) << (8 * i);
                 bytes[3 + a] |= uint32_t(std::min(255.0, std::max(0.0, qh))) << (8 * i);
             }
@@ -336,7 +361,39 @@ std::vector<uint4> buildNode4(const LrlSceneView* s, const std::vector<uint32_t>
         q[3] = make_uint4(refs[2], refs[3], expo[1] << 23, expo[2] << 23);
     }
     depthOut = depth;
+    tightened = 0;
+    for (uint32_t b = 0; b < s->bvhNodeNum; ++b) if (bvh[b].geometry && bvh[b].bound.leftChild && parked(bvh[b], b).inner) ++tightened;
     return out;
+}
+
+// the primitives' own boxes, for buildNode4 (callers' trees); both return whether a primitive left the box it had
+bool ownBoxPut(float* q, const float mn[3], const float mx[3]) {
+    bool left = false;
+    for (int a = 0; a < 3; ++a) {
+        left |= !(q[a] <= mn[a] && mx[a] <= q[3 + a]);
+        q[a] = mn[a]; q[3 + a] = mx[a];
+    }
+    return left;
+}
+bool ownTriangleBoxes(LrlContext* c, uint32_t first, uint32_t count, const LrlTriangle* tris) {
+    std::vector<float>& own = c->ownBox[2];
+    if (own.size() < size_t(first + count) * 6) return true;      // (not kept for this scene)
+    bool left = false;
+    for (uint32_t i = 0; i < count; ++i) {
+        const LrlTriangle& t = tris[i];
+        float mn[3], mx[3];
+        for (int a = 0; a < 3; ++a) {
+            mn[a] = std::min(t.p1[a], std::min(t.p2[a], t.p3[a]));
+            mx[a] = std::max(t.p1[a], std::max(t.p2[a], t.p3[a]));
+        }
+        left |= ownBoxPut(&own[size_t(first + i) * 6], mn, mx);
+    }
+    return left;
+}
+// Primitives changed under a caller's tree.  Its boxes are the contract again (the Pool demo never rebuilds: the water's leaf boxes
+// were made tall enough for every wave, Pool/Pool.cpp:250-263), until the next tree arrives.
+void ownBoxesStale(LrlContext* c) {
+    if (c->haveLoose) c->looseInUse = true;
 }
 
 // TrianglePre for [first, first+count): materials interned on the host, geometry on the device.
@@ -602,7 +659,7 @@ int lrl_destroy(LrlContext* c) {
     if (!c) return LRL_ERR_INVALID_ARG;
     (void)hipSetDevice(c->device);
     (void)hipStreamSynchronize(c->stream);
-    for (DevBuf* b : {&c->primMin, &c->primMax, &c->buildScratch, &c->buildInfo, &c->waterPoints, &c->waterTris, &c->waterMat, &c->nodes, &c->nodes32, &c->triHot, &c->triCold, &c->materials, &c->spheres, &c->circles, &c->cylinders, &c->cones, &c->lights,
+    for (DevBuf* b : {&c->primMin, &c->primMax, &c->buildScratch, &c->buildInfo, &c->waterPoints, &c->waterTris, &c->waterMat, &c->nodes, &c->nodes32, &c->nodes32Loose, &c->triHot, &c->triCold, &c->materials, &c->spheres, &c->circles, &c->cylinders, &c->cones, &c->lights,
                       &c->tex, &c->cube, &c->triStage, &c->matStage, &c->transDev, &c->outDev, &c->hitDev, &c->counterDev, &c->decayDev, &c->timelineDev, &c->wfArena})
         release(*b);
     for (auto& e : c->timingEvents) { (void)hipEventDestroy(e.first); (void)hipEventDestroy(e.second); }
@@ -665,11 +722,22 @@ static int uploadCallerTree(LrlContext* c, const LrlSceneView* s, uint32_t& recC
     HIP_TRY(c, hipStreamSynchronize(c->stream));
     // the same tree collapsed to four children per node with 8-bit child boxes, for the FAST lean kernel (lrl_lean.inc)
     uint32_t depth4 = 0;
-    std::vector<uint4> node4 = buildNode4(s, recOf, recCount, depth4);
+    size_t tightened = 0, none = 0;
+    std::vector<uint4> node4 = buildNode4(s, c->ownBox, recOf, recCount, depth4, tightened);
     c->node4Depth = depth4;
     rc = upload(c, c->nodes32, node4.data(), node4.size() * sizeof(uint4));
     if (rc) return rc;
     HIP_TRY(c, hipStreamSynchronize(c->stream));
+    c->haveLoose = c->looseInUse = false;
+    c->parkedTight = uint32_t(tightened);
+    if (tightened) {      // the same tree without them, for when the primitives move under it (ownBoxesStale)
+        node4 = buildNode4(s, nullptr, recOf, recCount, depth4, none);
+        rc = upload(c, c->nodes32Loose, node4.data(), node4.size() * sizeof(uint4));
+        if (rc) return rc;
+        HIP_TRY(c, hipStreamSynchronize(c->stream));
+        c->haveLoose = true;
+    }
+    if (c->tuning.debug) std::fprintf(stderr, "lrl: %zu primitives parked in inner nodes are bounded by their own boxes in the four-wide tree\n", tightened);
     return LRL_OK;
 }
 
@@ -701,6 +769,21 @@ int lrl_scene_upload(LrlContext* c, const LrlSceneView* s) {
 
     // nodes: the reference's 64-B own-box records -> 64-B inner records that hold both children's boxes
     uint32_t recCount = 1;
+    for (auto& v : c->ownBox) { v.clear(); v.shrink_to_fit(); }
+    c->haveLoose = c->looseInUse = false;
+    c->parkedTight = 0;
+    if (!deviceBuild) {
+        if (g.triangleNum && s->trianglesOrigin) {
+            c->ownBox[2].assign(size_t(g.triangleNum) * 6, 0.0f);
+            (void)ownTriangleBoxes(c, 0, g.triangleNum, s->trianglesOrigin);
+        }
+        const void* const arrays[7] = {nullptr, nullptr, nullptr, s->spheres, s->circles, s->cylinders, s->cones};
+        const uint32_t counts[7] = {0, 0, 0, g.sphereNum, g.circleNum, g.cylinderNum, g.coneNum};
+        for (uint32_t kind = 3; kind <= 6; ++kind) {
+            c->ownBox[kind].resize(size_t(counts[kind]) * 6);
+            for (uint32_t i = 0; i < counts[kind]; ++i) otherBox(kind, arrays[kind], i, &c->ownBox[kind][size_t(i) * 6], &c->ownBox[kind][size_t(i) * 6 + 3]);
+        }
+    }
     if (!deviceBuild && (rc = uploadCallerTree(c, s, recCount))) return rc;
     if (!deviceBuild && c->tuning.debug) std::fprintf(stderr, "lrl: binary nodes %u (depth %u), four-wide tree depth %u\n", s->bvhNodeNum, depth, c->node4Depth);
     if (deviceBuild) {
@@ -804,6 +887,7 @@ int lrl_scene_update_triangles(LrlContext* c, uint32_t first, uint32_t count, co
     if (uint64_t(first) + count > c->num.triangleNum) return fail(c, LRL_ERR_INVALID_ARG, "triangle range out of bounds");
     HIP_TRY(c, hipSetDevice(c->device));
     if (int rc0 = orderAfterRenders(c)) return rc0;
+    if (count && ownTriangleBoxes(c, first, count, tris)) ownBoxesStale(c);      // (the same triangles again, as the Pool demo sends them every frame: nothing moved)
     return runTrianglePre(c, first, count, tris);
 }
 
@@ -825,6 +909,7 @@ int lrl_scene_update_triangles_noalloc(LrlContext* c, uint32_t first, uint32_t c
             return fail(c, LRL_ERR_LIMIT, "lrl_scene_update_triangles_noalloc: a triangle carries a material that is not in the scene's table (adding one allocates); use lrl_scene_update_triangles");
         c->noallocMat[i] = it->second;
     }
+    if (ownTriangleBoxes(c, first, count, tris)) ownBoxesStale(c);      // (written in place: the vector has its size since the scene came)
     unsigned char* const area = static_cast<unsigned char*>(c->noallocScratch);
     LrlTriangle* const stageTris = reinterpret_cast<LrlTriangle*>(area);
     uint32_t* const stageMat = reinterpret_cast<uint32_t*>(area + size_t(LRL_NOALLOC_MAX_TRIANGLES) * sizeof(LrlTriangle));
@@ -868,6 +953,20 @@ int lrl_scene_update_primitives(LrlContext* c, uint32_t kind, uint32_t first, ui
     if (kind == LRL_PRIM_CIRCLE) {                       // CirclePre on the new records only (normalising twice is not the identity)
         HIP_TRY(c, lrl_launch_circle_pre(static_cast<LrlCircle*>(c->circles.p) + first, count, c->stream));
         HIP_TRY(c, hipStreamSynchronize(c->stream));
+    }
+    bool left = c->ownBox[kind].size() < size_t(first + count) * 6;
+    for (uint32_t i = 0; i < count && !left; ++i) {
+        float mn[3], mx[3];
+        otherBox(kind, records, i, mn, mx);
+        left = ownBoxPut(&c->ownBox[kind][size_t(first + i) * 6], mn, mx);
+    }
+    if (left) {      // (the boxes of the rest of the range, for the next tree)
+        for (uint32_t i = 0; i < count && c->ownBox[kind].size() >= size_t(first + count) * 6; ++i) {
+            float mn[3], mx[3];
+            otherBox(kind, records, i, mn, mx);
+            (void)ownBoxPut(&c->ownBox[kind][size_t(first + i) * 6], mn, mx);
+        }
+        ownBoxesStale(c);
     }
     if (c->deviceBuilt) {                                // their leaf boxes, for lrl_scene_rebuild_bvh
         const uint32_t before[7] = {0, 0, 0, 0, g.sphereNum, g.sphereNum + g.circleNum, g.sphereNum + g.circleNum + g.cylinderNum};
@@ -1603,6 +1702,10 @@ int lrl_water_step(LrlContext* c, uint32_t substeps) {
     HIP_TRY(c, hipSetDevice(c->device));
     if (int rc0 = orderAfterRenders(c)) return rc0;
     const uint32_t count = 2u * (c->waterGX - 1) * (c->waterGY - 1);
+    if (c->ownBox[2].size() >= size_t(c->waterFirst + count) * 6) {      // where the water's triangles are now is known on the device only
+        for (uint32_t i = 0; i < count; ++i) { float* q = &c->ownBox[2][size_t(c->waterFirst + i) * 6]; q[0] = 1.0f; q[3] = 0.0f; }
+    }
+    ownBoxesStale(c);
     HIP_TRY(c, lrl_launch_water_run(static_cast<float4*>(c->waterPoints.p), c->waterGX, c->waterGY, c->waterK, c->waterDt, substeps,
                                     static_cast<LrlTriangle*>(c->waterTris.p), c->stream));
     HIP_TRY(c, lrl_launch_triangle_pre(static_cast<const LrlTriangle*>(c->waterTris.p), static_cast<const uint32_t*>(c->waterMat.p), c->waterFirst, count,
@@ -1628,6 +1731,7 @@ int lrl_scene_info(const LrlContext* c, LrlSceneInfo* out) {
     if (!c->haveScene) return LRL_ERR_NO_SCENE;
     out->bvhNodes = c->nodeNum; out->bvhRecords = c->recNum; out->bvhDepth = c->bvhDepth; out->wideDepth = c->node4Depth;
     out->deviceBuilt = c->deviceBuilt ? 1u : 0u; out->materials = uint32_t(c->materialTable.size());
+    out->parkedOwnBoxes = c->looseInUse ? 0u : c->parkedTight;
     return LRL_OK;
 }
 
