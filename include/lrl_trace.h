@@ -275,11 +275,12 @@ typedef struct LrlSceneInfo {
     uint32_t wideDepth;      /* depth of the four-wide tree                                                                */
     uint32_t deviceBuilt;    /* 1: built by the library on the device                                                      */
     uint32_t materials;      /* distinct Color records                                                                     */
-    uint32_t parkedOwnBoxes; /* a caller's tree: primitives parked in inner nodes that the four-wide tree of the FAST kernels
-                                bounds by their own boxes instead of their node's (the reference tests such a primitive whenever
-                                the ray enters the node).  0 once a primitive has left the box it had at the last tree (update
-                                calls, water steps): then the caller's boxes alone decide, as the reference's do when the Pool's
-                                water moves under its fixed tree (Pool/Pool.cpp:250-263), until the next lrl_scene_update_bvh.   */
+    uint32_t ownBoxes;       /* a caller's tree: triangles that the four-wide tree of the FAST kernels bounds by their own boxes,
+                                more tightly than the caller's tree does (one parked in an inner node, which the reference tests
+                                whenever the ray enters the node; one whose leaf box was made larger than it is).  0 once a
+                                triangle has left the box it had when the tree came (update calls, water steps): then the
+                                caller's boxes alone decide, as the reference's do while the Pool's water moves under its fixed
+                                tree (Pool/Pool.cpp:250-263), until the next lrl_scene_update_bvh.                               */
 } LrlSceneInfo;
 int lrl_scene_info(const LrlContext* ctx, LrlSceneInfo* out);
 typedef struct LrlRenderInfo {       /* of the last wavefront-pipeline render */

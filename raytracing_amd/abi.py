@@ -70,7 +70,7 @@ class Tuning(C.Structure):
 
 
 class SceneInfo(C.Structure):
-    _fields_ = [(n, C.c_uint32) for n in ("bvhNodes", "bvhRecords", "bvhDepth", "wideDepth", "deviceBuilt", "materials", "parkedOwnBoxes")]
+    _fields_ = [(n, C.c_uint32) for n in ("bvhNodes", "bvhRecords", "bvhDepth", "wideDepth", "deviceBuilt", "materials", "ownBoxes")]
 
 
 class RenderInfo(C.Structure):

@@ -66,10 +66,10 @@ struct LrlContext {
     uint32_t texW = 0, texH = 0, texL = 0, cubeSize = 0;
     std::vector<LrlColor> materialTable;
     std::unordered_map<ColorKey, uint32_t, ColorHash> materialIndex;
-    // callers' trees: the primitives' own boxes by BVH geometry code (six floats each, min > max: not known), kept current by the
-    // update calls; the four-wide tree bounds a primitive that the caller parked in an inner node by them (buildNode4)
-    std::vector<float> ownBox[7];
-    uint32_t parkedTight = 0;     // parked primitives that nodes32 bounds by their own boxes
+    // callers' trees: the triangles' own boxes (six floats each, min > max: not known), kept current by the update calls; the
+    // four-wide tree is fitted to them (fitOwnBoxes)
+    std::vector<float> ownBox;
+    uint32_t parkedTight = 0;     // triangles that nodes32 bounds by their own boxes (fitOwnBoxes)
     bool haveLoose = false;       // nodes32Loose holds the same four-wide tree with the caller's boxes only
     bool looseInUse = false;      // primitives changed under the caller's tree since it came: its boxes alone are the contract (ownBoxesStale)
 
@@ -235,9 +235,82 @@ std::vector<uchar4> bgrToRgbx(const uint8_t* bgr, size_t texels) {
 }
 
 
+// The caller's tree refitted to the primitives' own boxes, for the four-wide tree (buildNode4).
+// The reference tests a primitive parked in an inner node whenever the ray enters that node's box, which spans a whole subtree, and the
+// Pool's tree has leaf boxes as tall as the highest wave (Pool/Pool.cpp:250-263).  While the primitives are where they were when the tree
+// came, a box fitted to the primitive says the same for every ray that can hit it and turns most of the others away:
+//   park[b] = the parked primitive's own box                      (its node's box where the own box is not known or pokes out of it)
+//   node[b] = leaf: the primitive's own box (same rule); inner: union of park[b] and the children's node[] boxes
+// Only for a nested tree (every child's box inside its parent's) and own boxes inside the caller's: then a ray that hits a primitive reaches
+// it through either set of boxes, and the fitted ones (nested as well, a margin wider than the own boxes) only turn away rays that cannot hit.  `count`: primitives bounded more tightly than by the caller's tree.
+struct FittedBoxes { std::vector<float> node, park; size_t count = 0; };
+bool fitOwnBoxes(const LrlSceneView* s, const std::vector<float>& ownBox, FittedBoxes& f) {
+    const LrlBVHNode* bvh = s->bvh;
+    const uint32_t N = s->bvhNodeNum;
+    f.node.assign(size_t(N) * 6, 0.0f);
+    f.park.assign(size_t(N) * 6, 0.0f);
+    f.count = 0;
+    auto callers = [&](uint32_t b, float* q) { for (int a = 0; a < 3; ++a) { q[a] = bvh[b].bound.min[a]; q[3 + a] = bvh[b].bound.max[a]; } };
+    float scale = 0.0f;       // of the coordinates the slab arithmetic works with
+    for (int a = 0; a < 3 && N; ++a) scale = std::max(scale, std::max(std::fabs(bvh[0].bound.min[a]), std::fabs(bvh[0].bound.max[a])));
+    const float pad = std::ldexp(scale, -14);
+    auto inside = [](const float* q, const float* outer) {
+        for (int a = 0; a < 3; ++a) if (!(q[a] <= q[3 + a]) || q[a] < outer[a] || q[3 + a] > outer[3 + a]) return false;
+        return true;
+    };
+    // own box of node b's primitive into q if it is known and lies in the caller's box; else the caller's box.  -> strictly tighter
+    auto own = [&](uint32_t b, float* q, bool parked) {
+        const LrlBVHNode& n = bvh[b];
+        float outer[6];
+        callers(b, outer);
+        std::memcpy(q, outer, sizeof(outer));
+        // triangles only: the other kinds go through the kernels' cold path, which is cheapest when the lanes of a wave take it together,
+        // on arrival at the node (C1, where every kind is parked near the root: 1.53 ms of trace kernels as the caller's tree has them,
+        // 1.63 ms with own boxes for all kinds)
+        if (n.geometry != 2) return false;
+        const std::vector<float>& o = ownBox;
+        const size_t at = size_t(n.geometryNum) * 6;
+        if (at + 6 > o.size() || !inside(&o[at], outer)) return false;
+        // with a margin on every side: a hit on the box's face (every hit on a triangle that lies in an axis plane, every hit on an edge
+        // that two neighbours' boxes share) must enter the box safely before the hit's distance, or one of two primitives at exactly
+        // the same distance would be turned away by the rounding of the slab arithmetic instead of being decided by its code
+        // (tests/test_gpu_parity.py::test_hand_over_kernels_agree, the Pool seen along its grid's diagonal)
+        for (int a = 0; a < 3; ++a) { q[a] = o[at + a] - pad; q[3 + a] = o[at + 3 + a] + pad; }
+        return parked || std::memcmp(&o[at], outer, sizeof(outer)) != 0;
+    };
+    for (uint32_t b = N; b-- > 0;) {      // pre-order: children come after their parent
+        const LrlBVHNode& n = bvh[b];
+        float* q = &f.node[size_t(b) * 6];
+        if (!n.bound.leftChild) {
+            if (n.geometry) f.count += own(b, q, false) ? 1 : 0;
+            else callers(b, q);
+            continue;
+        }
+        float outer[6];
+        callers(b, outer);
+        bool any = false;
+        auto join = [&](const float* c) {
+            for (int a = 0; a < 3; ++a) { q[a] = any ? std::min(q[a], c[a]) : c[a]; q[3 + a] = any ? std::max(q[3 + a], c[3 + a]) : c[3 + a]; }
+            any = true;
+        };
+        if (n.geometry) { f.count += own(b, &f.park[size_t(b) * 6], true) ? 1 : 0; join(&f.park[size_t(b) * 6]); }
+        const uint32_t kids[2] = {b + 1, uint32_t(n.bound.rightChild)};
+        for (int k = 0; k < (n.bound.rightChild ? 2 : 1); ++k) {
+            float cb[6];
+            callers(kids[k], cb);
+            if (!inside(cb, outer)) { f = FittedBoxes(); return false; }      // not nested: the caller's boxes as they are
+            join(&f.node[size_t(kids[k]) * 6]);
+        }
+    }
+    // (few gainers: not worth the second copy of the tree that ownBoxesStale falls back to.  C2's tree parks 0.5 % of its triangles)
+    if (f.count * 64 < ownBox.size() / 6) { f = FittedBoxes(); return false; }
+    return true;
+}
+
 // Four-wide, compressed repack of the caller's binary tree for the FAST lean kernel (lrl_lean.inc).  A node's items are
 // its parked primitive and its children; an inner child is replaced by ITS items while the node stays within four (largest
-// box first).  A parked primitive is bounded by its own box where that is known (ownBox; nullptr: by its node's, as the reference tests it).  The node of binary inner node b is stored at b's record index (recOf[b], the index `recs` uses), so refs mean
+// box first).  Boxes: the caller's, or the fitted ones (fitOwnBoxes).  The node of binary inner node b is stored at b's record index
+// (recOf[b], the index `recs` uses), so refs mean
 // the same in both trees and a ray can change from one to the other at any ref; record indices of binary nodes that were
 // merged into their parent stay unused.  64 B per node:
 //   {origin.x, origin.y, origin.z, unit.x}                       origin = min corner of the items' boxes; unit = per-axis
@@ -245,38 +318,27 @@ std::vector<uchar4> bgrToRgbx(const uint8_t* bgr, size_t texels) {
 //   {lo.x of items 0..3 (one byte each), lo.y, lo.z, hi.x}       box = origin + byte * unit, rounded outwards
 //   {hi.y, hi.z, ref0, ref1}  {ref2, ref3, unit.y, unit.z}       ref: record index, LRL_REF_LEAF | primitive, or LRL_REF_EMPTY4 with an
 //                                                                inverted box (lo 255, hi 0) for an empty slot
-std::vector<uint4> buildNode4(const LrlSceneView* s, const std::vector<float>* ownBox, const std::vector<uint32_t>& recOf, uint32_t recCount, uint32_t& depthOut, size_t& tightened) {
+std::vector<uint4> buildNode4(const LrlSceneView* s, const FittedBoxes* fitted, const std::vector<uint32_t>& recOf, uint32_t recCount, uint32_t& depthOut) {
     const LrlBVHNode* bvh = s->bvh;
     struct Item { bool inner; uint32_t ref; float lo[3], hi[3]; };      // inner: binary node index; else primitive bits
     auto primOf = [&](const LrlBVHNode& n) { return (uint32_t(n.geometry) << LRL_PRIM_TYPE_SHIFT) | (n.geometryNum & LRL_PRIM_INDEX_MASK); };
-    auto boxed = [&](bool inner, uint32_t ref, uint32_t boxOf) {
+    auto boxed = [&](bool inner, uint32_t ref, uint32_t boxOf, bool parked) {
         Item it{inner, ref, {0, 0, 0}, {0, 0, 0}};
-        for (int a = 0; a < 3; ++a) { it.lo[a] = bvh[boxOf].bound.min[a]; it.hi[a] = bvh[boxOf].bound.max[a]; }
-        return it;
-    };
-    // A primitive parked in an inner node: the reference tests it whenever the ray enters that node's box, which spans the
-    // whole subtree.  Its own box says the same for every ray that can hit it and turns most of the others away, as long as
-    // it lies within the node's box (a tree where it does not keeps the node's box: then the node's box decides, as in the reference).
-    auto parked = [&](const LrlBVHNode& n, uint32_t b) {
-        Item it = boxed(false, primOf(n), b);
-        if (!ownBox || n.geometry >= 7) return it;
-        const std::vector<float>& own = ownBox[n.geometry];
-        const size_t at = size_t(n.geometryNum) * 6;
-        if (at + 6 > own.size()) return it;
-        const float* q = &own[at];
-        for (int a = 0; a < 3; ++a) if (!(q[a] <= q[3 + a]) || q[a] < it.lo[a] || q[3 + a] > it.hi[a]) return it;
-        for (int a = 0; a < 3; ++a) { it.lo[a] = q[a]; it.hi[a] = q[3 + a]; }
-        it.inner = true;      // (for the count below; the caller clears it)
+        if (fitted) {
+            const float* q = parked ? &fitted->park[size_t(boxOf) * 6] : &fitted->node[size_t(boxOf) * 6];
+            for (int a = 0; a < 3; ++a) { it.lo[a] = q[a]; it.hi[a] = q[3 + a]; }
+        } else
+            for (int a = 0; a < 3; ++a) { it.lo[a] = bvh[boxOf].bound.min[a]; it.hi[a] = bvh[boxOf].bound.max[a]; }
         return it;
     };
     auto asItem = [&](uint32_t cnode, Item* out, int& k) {
-        if (bvh[cnode].bound.leftChild) out[k++] = boxed(true, cnode, cnode);
-        else if (bvh[cnode].geometry) out[k++] = boxed(false, primOf(bvh[cnode]), cnode);
+        if (bvh[cnode].bound.leftChild) out[k++] = boxed(true, cnode, cnode, false);
+        else if (bvh[cnode].geometry) out[k++] = boxed(false, primOf(bvh[cnode]), cnode, false);
     };
     auto contents = [&](uint32_t b, Item* out) -> int {
         const LrlBVHNode& n = bvh[b];
         int k = 0;
-        if (n.geometry) { out[k] = parked(n, b); out[k++].inner = false; }
+        if (n.geometry) out[k++] = boxed(false, primOf(n), b, true);
         if (n.bound.leftChild) {
             asItem(b + 1, out, k);
             if (n.bound.rightChild) asItem(uint32_t(n.bound.rightChild), out, k);
@@ -284,8 +346,8 @@ std::vector<uint4> buildNode4(const LrlSceneView* s, const std::vector<float>* o
         return k;
     };
     auto area = [&](uint32_t b) {
-        const LrlBound& q = bvh[b].bound;
-        float dx = q.max[0] - q.min[0], dy = q.max[1] - q.min[1], dz = q.max[2] - q.min[2];
+        const Item q = boxed(true, b, b, false);
+        float dx = q.hi[0] - q.lo[0], dy = q.hi[1] - q.lo[1], dz = q.hi[2] - q.lo[2];
         return dx * dy + dy * dz + dz * dx;
     };
     auto fb = [](float f) { uint32_t v; std::memcpy(&v, &f, 4); return v; };
@@ -361,8 +423,6 @@ std::vector<uint4> buildNode4(const LrlSceneView* s, const std::vector<float>* o
         q[3] = make_uint4(refs[2], refs[3], expo[1] << 23, expo[2] << 23);
     }
     depthOut = depth;
-    tightened = 0;
-    for (uint32_t b = 0; b < s->bvhNodeNum; ++b) if (bvh[b].geometry && bvh[b].bound.leftChild && parked(bvh[b], b).inner) ++tightened;
     return out;
 }
 
@@ -376,7 +436,7 @@ bool ownBoxPut(float* q, const float mn[3], const float mx[3]) {
     return left;
 }
 bool ownTriangleBoxes(LrlContext* c, uint32_t first, uint32_t count, const LrlTriangle* tris) {
-    std::vector<float>& own = c->ownBox[2];
+    std::vector<float>& own = c->ownBox;
     if (own.size() < size_t(first + count) * 6) return true;      // (not kept for this scene)
     bool left = false;
     for (uint32_t i = 0; i < count; ++i) {
@@ -722,22 +782,25 @@ static int uploadCallerTree(LrlContext* c, const LrlSceneView* s, uint32_t& recC
     HIP_TRY(c, hipStreamSynchronize(c->stream));
     // the same tree collapsed to four children per node with 8-bit child boxes, for the FAST lean kernel (lrl_lean.inc)
     uint32_t depth4 = 0;
-    size_t tightened = 0, none = 0;
-    std::vector<uint4> node4 = buildNode4(s, c->ownBox, recOf, recCount, depth4, tightened);
+    FittedBoxes fitted;
+    const bool fit = fitOwnBoxes(s, c->ownBox, fitted);
+    std::vector<uint4> node4 = buildNode4(s, fit ? &fitted : nullptr, recOf, recCount, depth4);
+    const size_t tightened = fit ? fitted.count : 0;
+    fitted = FittedBoxes();
     c->node4Depth = depth4;
     rc = upload(c, c->nodes32, node4.data(), node4.size() * sizeof(uint4));
     if (rc) return rc;
     HIP_TRY(c, hipStreamSynchronize(c->stream));
     c->haveLoose = c->looseInUse = false;
     c->parkedTight = uint32_t(tightened);
-    if (tightened) {      // the same tree without them, for when the primitives move under it (ownBoxesStale)
-        node4 = buildNode4(s, nullptr, recOf, recCount, depth4, none);
+    if (fit) {      // the same tree with the caller's boxes, for when the primitives move under it (ownBoxesStale)
+        node4 = buildNode4(s, nullptr, recOf, recCount, depth4);
         rc = upload(c, c->nodes32Loose, node4.data(), node4.size() * sizeof(uint4));
         if (rc) return rc;
         HIP_TRY(c, hipStreamSynchronize(c->stream));
         c->haveLoose = true;
     }
-    if (c->tuning.debug) std::fprintf(stderr, "lrl: %zu primitives parked in inner nodes are bounded by their own boxes in the four-wide tree\n", tightened);
+    if (c->tuning.debug) std::fprintf(stderr, "lrl: the four-wide tree bounds %zu primitives by their own boxes\n", tightened);
     return LRL_OK;
 }
 
@@ -769,19 +832,13 @@ int lrl_scene_upload(LrlContext* c, const LrlSceneView* s) {
 
     // nodes: the reference's 64-B own-box records -> 64-B inner records that hold both children's boxes
     uint32_t recCount = 1;
-    for (auto& v : c->ownBox) { v.clear(); v.shrink_to_fit(); }
+    c->ownBox.clear(); c->ownBox.shrink_to_fit();
     c->haveLoose = c->looseInUse = false;
     c->parkedTight = 0;
     if (!deviceBuild) {
         if (g.triangleNum && s->trianglesOrigin) {
-            c->ownBox[2].assign(size_t(g.triangleNum) * 6, 0.0f);
+            c->ownBox.assign(size_t(g.triangleNum) * 6, 0.0f);
             (void)ownTriangleBoxes(c, 0, g.triangleNum, s->trianglesOrigin);
-        }
-        const void* const arrays[7] = {nullptr, nullptr, nullptr, s->spheres, s->circles, s->cylinders, s->cones};
-        const uint32_t counts[7] = {0, 0, 0, g.sphereNum, g.circleNum, g.cylinderNum, g.coneNum};
-        for (uint32_t kind = 3; kind <= 6; ++kind) {
-            c->ownBox[kind].resize(size_t(counts[kind]) * 6);
-            for (uint32_t i = 0; i < counts[kind]; ++i) otherBox(kind, arrays[kind], i, &c->ownBox[kind][size_t(i) * 6], &c->ownBox[kind][size_t(i) * 6 + 3]);
         }
     }
     if (!deviceBuild && (rc = uploadCallerTree(c, s, recCount))) return rc;
@@ -953,20 +1010,6 @@ int lrl_scene_update_primitives(LrlContext* c, uint32_t kind, uint32_t first, ui
     if (kind == LRL_PRIM_CIRCLE) {                       // CirclePre on the new records only (normalising twice is not the identity)
         HIP_TRY(c, lrl_launch_circle_pre(static_cast<LrlCircle*>(c->circles.p) + first, count, c->stream));
         HIP_TRY(c, hipStreamSynchronize(c->stream));
-    }
-    bool left = c->ownBox[kind].size() < size_t(first + count) * 6;
-    for (uint32_t i = 0; i < count && !left; ++i) {
-        float mn[3], mx[3];
-        otherBox(kind, records, i, mn, mx);
-        left = ownBoxPut(&c->ownBox[kind][size_t(first + i) * 6], mn, mx);
-    }
-    if (left) {      // (the boxes of the rest of the range, for the next tree)
-        for (uint32_t i = 0; i < count && c->ownBox[kind].size() >= size_t(first + count) * 6; ++i) {
-            float mn[3], mx[3];
-            otherBox(kind, records, i, mn, mx);
-            (void)ownBoxPut(&c->ownBox[kind][size_t(first + i) * 6], mn, mx);
-        }
-        ownBoxesStale(c);
     }
     if (c->deviceBuilt) {                                // their leaf boxes, for lrl_scene_rebuild_bvh
         const uint32_t before[7] = {0, 0, 0, 0, g.sphereNum, g.sphereNum + g.circleNum, g.sphereNum + g.circleNum + g.cylinderNum};
@@ -1702,8 +1745,8 @@ int lrl_water_step(LrlContext* c, uint32_t substeps) {
     HIP_TRY(c, hipSetDevice(c->device));
     if (int rc0 = orderAfterRenders(c)) return rc0;
     const uint32_t count = 2u * (c->waterGX - 1) * (c->waterGY - 1);
-    if (c->ownBox[2].size() >= size_t(c->waterFirst + count) * 6) {      // where the water's triangles are now is known on the device only
-        for (uint32_t i = 0; i < count; ++i) { float* q = &c->ownBox[2][size_t(c->waterFirst + i) * 6]; q[0] = 1.0f; q[3] = 0.0f; }
+    if (c->ownBox.size() >= size_t(c->waterFirst + count) * 6) {      // where the water's triangles are now is known on the device only
+        for (uint32_t i = 0; i < count; ++i) { float* q = &c->ownBox[size_t(c->waterFirst + i) * 6]; q[0] = 1.0f; q[3] = 0.0f; }
     }
     ownBoxesStale(c);
     HIP_TRY(c, lrl_launch_water_run(static_cast<float4*>(c->waterPoints.p), c->waterGX, c->waterGY, c->waterK, c->waterDt, substeps,
@@ -1731,7 +1774,7 @@ int lrl_scene_info(const LrlContext* c, LrlSceneInfo* out) {
     if (!c->haveScene) return LRL_ERR_NO_SCENE;
     out->bvhNodes = c->nodeNum; out->bvhRecords = c->recNum; out->bvhDepth = c->bvhDepth; out->wideDepth = c->node4Depth;
     out->deviceBuilt = c->deviceBuilt ? 1u : 0u; out->materials = uint32_t(c->materialTable.size());
-    out->parkedOwnBoxes = c->looseInUse ? 0u : c->parkedTight;
+    out->ownBoxes = c->looseInUse ? 0u : c->parkedTight;
     return LRL_OK;
 }
 
