@@ -69,7 +69,7 @@ def parse_args():
     ap.add_argument("--steps", type=int, default=0, help="0 = the workload's own (50 for c1/c2, 5 for c3/c5, 3 for c4)")
     ap.add_argument("--warmup", type=int, default=-1, help="-1 = the workload's own")
     ap.add_argument("--mode", default="fast", choices=["fast", "parity"])
-    ap.add_argument("--builder", default="", choices=["", "reference", "median", "device"],
+    ap.add_argument("--builder", default="", choices=["", "reference", "median", "sah", "device"],
                     help="who builds the BVH: the restated reference builder (host), a median-split host builder, or the library on the device")
     ap.add_argument("--subdivisions", type=int, default=2)
     ap.add_argument("--width", type=int, default=0)

@@ -119,7 +119,7 @@ class HostModel:
 
     # ---- model.dataInit() ----
     def data_init(self, builder="reference"):
-        self._ck(self._L.lrlh_data_init(self._h, {"reference": 0, "median": 1, "none": 2}[builder]))      # "none": counts only, no tree
+        self._ck(self._L.lrlh_data_init(self._h, {"reference": 0, "median": 1, "none": 2, "sah": 3}[builder]))      # "none": counts only, no tree
 
     def scene_view(self):
         v = abi.SceneView()

@@ -358,7 +358,7 @@ struct Model {
         float min[3], max[3], centre[3], weight;
         uint32_t geometry, geometryNum;
     };
-    enum class Builder { Reference, Median };
+    enum class Builder { Reference, Median, Sah };
     Builder builder = Builder::Reference;
 
     static void boxFromDisc(float const c[3], float const n[3], float R, float mn[3], float mx[3]) {
@@ -491,6 +491,59 @@ struct Model {
         // tie order of BVH.exe@0x140005fa5-0x140005fc3
         unsigned axis = (var[1] > var[0]) ? (var[1] <= var[2] ? 2u : 1u) : (var[0] > var[2] ? 0u : 2u);
         float meanAxis = float(mean[axis]);
+        if (cx.builder == Builder::Sah) {
+            // binned surface-area heuristic (not in the reference; a yardstick for what the tree's quality is worth to the tracer):
+            // 16 bins over the centres' extent on each axis, one primitive per leaf, no in-node primitives
+            constexpr int B = 16;
+            float cmn[3] = {FLT_MAX, FLT_MAX, FLT_MAX}, cmx[3] = {-FLT_MAX, -FLT_MAX, -FLT_MAX};
+            for (size_t i = b; i < e; ++i)
+                for (int k = 0; k < 3; ++k) { cmn[k] = std::min(cmn[k], L[cx.idx[i]].centre[k]); cmx[k] = std::max(cmx[k], L[cx.idx[i]].centre[k]); }
+            auto half = [](const float* lo, const float* hi) { float dx = hi[0] - lo[0], dy = hi[1] - lo[1], dz = hi[2] - lo[2]; return dx * dy + dy * dz + dz * dx; };
+            double best = 1e300; int bestAxis = -1, bestBin = 0;
+            for (int k = 0; k < 3; ++k) {
+                if (!(cmx[k] > cmn[k])) continue;
+                struct Bin { float lo[3], hi[3]; size_t n; } bins[B];
+                for (auto& q : bins) { for (int a = 0; a < 3; ++a) { q.lo[a] = FLT_MAX; q.hi[a] = -FLT_MAX; } q.n = 0; }
+                const float scale = float(B) / (cmx[k] - cmn[k]);
+                for (size_t i = b; i < e; ++i) {
+                    Leaf const& l = L[cx.idx[i]];
+                    int bi = std::min(B - 1, int((l.centre[k] - cmn[k]) * scale));
+                    for (int a = 0; a < 3; ++a) { bins[bi].lo[a] = std::min(bins[bi].lo[a], l.min[a]); bins[bi].hi[a] = std::max(bins[bi].hi[a], l.max[a]); }
+                    ++bins[bi].n;
+                }
+                double rightCost[B]; size_t rightN[B];
+                float lo[3] = {FLT_MAX, FLT_MAX, FLT_MAX}, hi[3] = {-FLT_MAX, -FLT_MAX, -FLT_MAX}; size_t n = 0;
+                for (int j = B - 1; j > 0; --j) {
+                    for (int a = 0; a < 3; ++a) { lo[a] = std::min(lo[a], bins[j].lo[a]); hi[a] = std::max(hi[a], bins[j].hi[a]); }
+                    n += bins[j].n; rightN[j] = n; rightCost[j] = n ? double(half(lo, hi)) * double(n) : 0.0;
+                }
+                for (int a = 0; a < 3; ++a) { lo[a] = FLT_MAX; hi[a] = -FLT_MAX; }
+                n = 0;
+                for (int j = 0; j + 1 < B; ++j) {
+                    for (int a = 0; a < 3; ++a) { lo[a] = std::min(lo[a], bins[j].lo[a]); hi[a] = std::max(hi[a], bins[j].hi[a]); }
+                    n += bins[j].n;
+                    if (!n || !rightN[j + 1]) continue;
+                    const double c = double(half(lo, hi)) * double(n) + rightCost[j + 1];
+                    if (c < best) { best = c; bestAxis = k; bestBin = j; }
+                }
+            }
+            size_t mid;
+            if (bestAxis < 0) { mid = b + (e - b) / 2; bestAxis = 0; }      // all centres coincide: by index
+            else {
+                const float scale = float(B) / (cmx[bestAxis] - cmn[bestAxis]);
+                auto it = std::stable_partition(cx.idx.begin() + b, cx.idx.begin() + e, [&](uint32_t x) {
+                    return std::min(B - 1, int((L[x].centre[bestAxis] - cmn[bestAxis]) * scale)) <= bestBin; });
+                mid = size_t(it - cx.idx.begin());
+            }
+            LrlBVHNode node{};
+            for (int k = 0; k < 3; ++k) { node.bound.min[k] = mn[k]; node.bound.max[k] = mx[k]; }
+            node.father = father; node.axis = unsigned(bestAxis);
+            node.bound.leftChild = 1;
+            emit(cx, b, mid, self, depth + 1);
+            node.bound.rightChild = int32_t(emit(cx, mid, e, self, depth + 1));
+            (*cx.out)[self] = node;
+            return self;
+        }
         if (cx.builder == Builder::Median) {
             // balanced alternative (not in the reference): object median on the axis of largest centre extent,
             // no in-node primitives; depth = ceil(log2 N), for scenes whose mean-split tree would pass 32 levels

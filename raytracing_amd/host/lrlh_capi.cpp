@@ -106,7 +106,7 @@ int lrlh_set_tex_raw(Handle* h, unsigned w, unsigned hh, unsigned layers, const 
 // model.dataInit(): counts + CPU BVH build.  builder: 0 = reference algorithm, 1 = balanced median.
 int lrlh_data_init(Handle* h, int builder) {
     return guarded([&] {
-        h->model.builder = builder == 1 ? Model::Builder::Median : Model::Builder::Reference;
+        h->model.builder = builder == 1 ? Model::Builder::Median : (builder == 3 ? Model::Builder::Sah : Model::Builder::Reference);
         if (builder == 2) h->model.dataInitWithoutTree();      // counts only: the tracer library builds the tree on the device
         else h->model.dataInit();
         if (h->poolWaterPending) { scenes::poolWaterSync(h->model); h->poolWaterPending = false; }   // Pool/Pool.cpp:649-650: after dataInit

@@ -135,7 +135,7 @@ def random_scene(seed, n_tri=300, n_sph=12):
 
 
 @pytest.mark.parametrize("seed", [1, 2, 3])
-@pytest.mark.parametrize("builder", ["reference", "median"])
+@pytest.mark.parametrize("builder", ["reference", "median", "sah"])
 def test_random_scenes_vs_oracle(tracer, seed, builder):
     m = random_scene(seed)
     m.data_init(builder)

@@ -125,13 +125,15 @@ def test_empty_scene_builds_a_dead_node():
     assert len(a["bvh"]) == 1 and a["bvh"]["geometry"][0] == 0 and a["bvh"]["leftChild"][0] == 0
 
 
-@pytest.mark.parametrize("builder", ["reference", "median"])
+@pytest.mark.parametrize("builder", ["reference", "median", "sah"])
 def test_bunny_bvh_invariants(builder):
     m = scenes.mesh_scene(subdivisions=0, builder=builder)
     depth = check_invariants(m)
     n = m.bvh_info()
     if builder == "median":
         assert depth.max() <= 18 and n["nodes"] == 2 * (77560 + 1) - 1
+    if builder == "sah":          # (the yardstick builder: one primitive per leaf, none parked)
+        assert n["nodes"] == 2 * (77560 + 1) - 1
     assert len(m.arrays()["triangles"]) == 77560
 
 
