@@ -303,7 +303,7 @@ bool fitOwnBoxes(const LrlSceneView* s, const std::vector<float>& ownBox, Fitted
         }
     }
     // (few gainers: not worth the second copy of the tree that ownBoxesStale falls back to.  C2's tree parks 0.5 % of its triangles)
-    if (f.count * 64 < ownBox.size() / 6) { f = FittedBoxes(); return false; }
+    if (f.count == 0 || f.count * 64 < ownBox.size() / 6) { f = FittedBoxes(); return false; }
     return true;
 }
 
