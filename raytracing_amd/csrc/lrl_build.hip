@@ -315,15 +315,18 @@ __global__ __launch_bounds__(256) void height4Kernel(uint32_t n, const uint32_t*
 __global__ __launch_bounds__(256) void fitLevelKernel(const float4* __restrict__ pmin, const float4* __restrict__ pmax, const uint32_t* __restrict__ idx, uint32_t n,
                                                       const uint2* __restrict__ children, uint32_t* doneAt, uint32_t launch, float4* nodeMin, float4* nodeMax,
                                                       uint32_t* heights, float4* recs, uint4* node4, uint32_t* h4, uint32_t* info) {
-    const uint32_t cur = blockIdx.x * 256u + threadIdx.x;
-    if (cur + 1u >= n || doneAt[cur] != 0u) return;
+    // (a grid-stride loop: late launches find nearly every node done, and dispatching 390 000 workgroups for 100 M nodes costs more than reading their stamps)
+    for (uint32_t cur = blockIdx.x * 256u + threadIdx.x; cur + 1u < n; cur += gridDim.x * 256u) {
+    if (doneAt[cur] != 0u) continue;
     const uint2 c = children[cur];
     const uint32_t cc[2] = {c.x, c.y};
+    bool ready = true;
     for (int k = 0; k < 2; ++k)
         if (!(cc[k] & LRL_REF_LEAF)) {
             const uint32_t d = doneAt[cc[k]];
-            if (d == 0u || d >= launch) return;
+            ready = ready && d != 0u && d < launch;
         }
+    if (!ready) continue;
     float4 mn[2], mx[2];
     uint32_t ref[2], h[2];
     for (int k = 0; k < 2; ++k) {
@@ -374,6 +377,7 @@ __global__ __launch_bounds__(256) void fitLevelKernel(const float4* __restrict__
         info[0] = height;
     }
     doneAt[cur] = launch;
+    }
 }
 
 }  // namespace lrl_build
@@ -443,7 +447,7 @@ hipError_t lrl_build_bvh(const float4* pmin, const float4* pmax, uint32_t n, flo
     // host looks at info[0] (the root's height, written by the launch that fits the root) every few launches
     uint32_t rootHeight = 0;
     for (uint32_t launch = 1; launch <= LRL_MAX_BVH_DEPTH + 1u; ++launch) {
-        hipLaunchKernelGGL(lrl_build::fitLevelKernel, grd, blk, 0, stream, pmin, pmax, idxB, n, children, counters, launch, nodeMin, nodeMax, heights, recs,
+        hipLaunchKernelGGL(lrl_build::fitLevelKernel, dim3(std::min<uint32_t>(grd.x, 32768u)), blk, 0, stream, pmin, pmax, idxB, n, children, counters, launch, nodeMin, nodeMax, heights, recs,
                            node4, h4, infoDev);
         if (launch >= 16u && (launch & 7u) == 0u) {
             if ((e = hipMemcpyAsync(&rootHeight, infoDev, 4, hipMemcpyDeviceToHost, stream)) != hipSuccess) return e;
