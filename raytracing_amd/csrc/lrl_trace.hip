@@ -110,6 +110,7 @@ struct LrlContext {
     std::vector<uint32_t> handoverThr;  // per iteration index; empty until first use
     uint32_t handoverRegime = 0;        // what the base thresholds were chosen for: 0 a sample in the caches, 1 a large launch, 2 a scene beyond the caches
     std::vector<uint32_t> swarmGrid;    // waves launched for the handed-over rays of that iteration (a grid-stride kernel)
+    std::vector<uint8_t> handoverIdle;  // per iteration: the last feedback saw no ray reach the threshold (the hand-over launch is left out until the next feedback pass)
     hipEvent_t evIter[4] = {nullptr, nullptr, nullptr, nullptr};
     bool hasTransmission = false;       // some material has t != 0: refraction stacks are needed
     uint32_t lastIterations = 0;
@@ -1265,6 +1266,7 @@ static int renderWavefront(LrlContext* c, const LrlRenderParams* p, const KScene
         c->handoverThr.resize(LRL_FEEDBACK_ITERS);
         for (uint32_t i = 0; i < LRL_FEEDBACK_ITERS; ++i) c->handoverThr[i] = baseThr(i);
         c->swarmGrid.assign(LRL_FEEDBACK_ITERS, contSlots);
+        c->handoverIdle.assign(LRL_FEEDBACK_ITERS, 0);
     }
     const float workLow = tn.workLow;
     c->workPerRay.resize(LRL_FEEDBACK_ITERS, 0.0f);
@@ -1279,6 +1281,7 @@ static int renderWavefront(LrlContext* c, const LrlRenderParams* p, const KScene
             uint32_t& t = c->handoverThr[i];
             const volatile uint32_t* h = c->contHost + size_t(i) * 8;
             const uint32_t asked = h[0];
+            c->handoverIdle[i] = asked == 0u;
             if (t == 0) continue;
             uint64_t work = 0;
             for (uint32_t w = 0; w < LRL_WORK_COUNTERS; ++w) work += h[1 + w];
@@ -1388,7 +1391,10 @@ static int renderWavefront(LrlContext* c, const LrlRenderParams* p, const KScene
             if (special) {
                 const uint32_t fi = std::min(iter, LRL_FEEDBACK_ITERS - 1);
                 wf.contCount = contCounts + (iter < LRL_WF_MAX_ITERATIONS ? iter : 0);
-                wf.handoverTrips = handoverFits ? c->handoverThr[fi] : 0u;
+                // an iteration whose rays all finished below the threshold at the last feedback runs without hand-over (the same rays, finished
+                // by the lean kernel as they were anyway) and without the launch that would find nothing: the default scene has 56 such
+                // iterations a frame, 9 us each; every feedback pass looks again
+                wf.handoverTrips = (handoverFits && (report || !c->handoverIdle[fi])) ? c->handoverThr[fi] : 0u;
                 wf.contWork = contWorkAll + size_t(fi) * LRL_WORK_COUNTERS * 32;
                 const bool compact = compactFrom != 0 && iter >= compactFrom && iter < LRL_WF_MAX_ITERATIONS;
                 wf.listCount = listCounts + size_t(iter < LRL_WF_MAX_ITERATIONS ? iter : 0) * LRL_LIST_KINDS;
