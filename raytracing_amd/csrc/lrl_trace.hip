@@ -248,9 +248,8 @@ struct FittedBoxes { std::vector<float> node, park; size_t count = 0; };
 bool fitOwnBoxes(const LrlSceneView* s, const std::vector<float>& ownBox, FittedBoxes& f) {
     const LrlBVHNode* bvh = s->bvh;
     const uint32_t N = s->bvhNodeNum;
-    f.node.assign(size_t(N) * 6, 0.0f);
-    f.park.assign(size_t(N) * 6, 0.0f);
-    f.count = 0;
+    f = FittedBoxes();
+    if (ownBox.empty()) return false;
     auto callers = [&](uint32_t b, float* q) { for (int a = 0; a < 3; ++a) { q[a] = bvh[b].bound.min[a]; q[3 + a] = bvh[b].bound.max[a]; } };
     float scale = 0.0f;       // of the coordinates the slab arithmetic works with
     for (int a = 0; a < 3 && N; ++a) scale = std::max(scale, std::max(std::fabs(bvh[0].bound.min[a]), std::fabs(bvh[0].bound.max[a])));
@@ -279,6 +278,16 @@ bool fitOwnBoxes(const LrlSceneView* s, const std::vector<float>& ownBox, Fitted
         for (int a = 0; a < 3; ++a) { q[a] = o[at + a] - pad; q[3 + a] = o[at + 3 + a] + pad; }
         return parked || std::memcmp(&o[at], outer, sizeof(outer)) != 0;
     };
+    // who gains, before anything is allocated (few gainers: not worth the second copy of the tree that ownBoxesStale falls back to; C2's
+    // tree parks 0.5 % of its triangles)
+    size_t gainers = 0;
+    for (uint32_t b = 0; b < N; ++b) {
+        float q[6];
+        if (bvh[b].geometry) gainers += own(b, q, bvh[b].bound.leftChild != 0) ? 1 : 0;
+    }
+    if (gainers == 0 || gainers * 64 < ownBox.size() / 6) return false;
+    f.node.assign(size_t(N) * 6, 0.0f);
+    f.park.assign(size_t(N) * 6, 0.0f);
     for (uint32_t b = N; b-- > 0;) {      // pre-order: children come after their parent
         const LrlBVHNode& n = bvh[b];
         float* q = &f.node[size_t(b) * 6];
@@ -303,8 +312,6 @@ bool fitOwnBoxes(const LrlSceneView* s, const std::vector<float>& ownBox, Fitted
             join(&f.node[size_t(kids[k]) * 6]);
         }
     }
-    // (few gainers: not worth the second copy of the tree that ownBoxesStale falls back to.  C2's tree parks 0.5 % of its triangles)
-    if (f.count == 0 || f.count * 64 < ownBox.size() / 6) { f = FittedBoxes(); return false; }
     return true;
 }
 
