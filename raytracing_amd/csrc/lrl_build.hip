@@ -15,6 +15,7 @@
 //      item): they are addressed by record index, so the ones no ray reaches cost nothing but their memory
 //   6. the height of the four-wide tree, bottom-up again (stack sizes of the trace kernels)
 // From LRL_BUILD_LEVELS_FROM primitives on, steps 4-6 are one kernel launched once per level of readiness (fitLevelKernel).
+// Step 3 has a second form (LrlTuning.deviceBuilder): PLOC, below.
 // Not the reference's tree: images agree with a host-built tree except where two primitives are hit at exactly the same
 // distance (tests/test_gpu_parity.py::test_device_built_bvh*).
 #include <hip/hip_runtime.h>
@@ -380,6 +381,157 @@ __global__ __launch_bounds__(256) void fitLevelKernel(const float4* __restrict__
     }
 }
 
+// ---- step 3, the other way: clusters merged bottom-up with their nearest neighbour in Morton order (PLOC, Meister & Bittner 2018) ----
+// Every cluster looks LRL_PLOC_RADIUS places to either side for the neighbour with which it would make the smallest box; pairs that chose
+// each other merge into a new inner node, the rest wait; the survivors are compacted and the round repeats until one cluster is left.
+// Inner nodes are numbered from the root down (root = 0, as the fit kernels expect): the t-th merge of the build is node n - 2 - t.
+#define LRL_PLOC_RADIUS 16      /* (8, 32 and 64 give the same frame times within 1 %) */
+DI float unionArea(const float4& amin, const float4& amax, const float4& bmin, const float4& bmax) {
+    const float dx = fmaxf(amax.x, bmax.x) - fminf(amin.x, bmin.x), dy = fmaxf(amax.y, bmax.y) - fminf(amin.y, bmin.y),
+                dz = fmaxf(amax.z, bmax.z) - fminf(amin.z, bmin.z);
+    return dx * dy + dy * dz + dz * dx;
+}
+__global__ __launch_bounds__(256) void plocInitKernel(const float4* __restrict__ pmin, const float4* __restrict__ pmax, const uint32_t* __restrict__ idx, uint32_t n,
+                                                      uint32_t* __restrict__ ref, float4* __restrict__ cmin, float4* __restrict__ cmax) {
+    const uint32_t i = blockIdx.x * 256u + threadIdx.x;
+    if (i >= n) return;
+    const uint32_t p = idx[i];
+    ref[i] = LRL_REF_LEAF | i;
+    cmin[i] = pmin[p]; cmax[i] = pmax[p];
+}
+__global__ __launch_bounds__(256) void plocNearestKernel(const float4* __restrict__ cmin, const float4* __restrict__ cmax, uint32_t cnt, uint32_t* __restrict__ nn) {
+    constexpr int RAD = LRL_PLOC_RADIUS;
+    __shared__ float4 smin[256 + 2 * RAD], smax[256 + 2 * RAD];
+    const int base = int(blockIdx.x * 256u) - RAD;
+    for (int t = int(threadIdx.x); t < 256 + 2 * RAD; t += 256) {
+        const int g = base + t;
+        if (g >= 0 && g < int(cnt)) { smin[t] = cmin[g]; smax[t] = cmax[g]; }
+    }
+    __syncthreads();
+    const int i = int(blockIdx.x * 256u + threadIdx.x);
+    if (i >= int(cnt)) return;
+    const int li = i - base;
+    const float4 mn = smin[li], mx = smax[li];
+    float best = INFINITY;
+    int bestJ = i;
+    // nearest places first, so that among equal boxes the nearer neighbour wins; the buddy i ^ 1 wins every tie (a run of identical boxes
+    // pairs off in one round instead of forming a chain that merges one pair a round)
+    for (int d = 1; d <= RAD; ++d)
+        for (int sgn = 0; sgn < 2; ++sgn) {
+            const int j = sgn ? i - d : i + d;
+            if (j < 0 || j >= int(cnt)) continue;
+            const float a = unionArea(mn, mx, smin[j - base], smax[j - base]);
+            if (a < best || (a == best && j == (i ^ 1))) { best = a; bestJ = j; }
+        }
+    nn[i] = uint32_t(bestJ);
+}
+__global__ __launch_bounds__(256) void plocMarkKernel(const uint32_t* __restrict__ nn, uint32_t cnt, uint32_t* __restrict__ merge, uint32_t* __restrict__ keep) {
+    const uint32_t i = blockIdx.x * 256u + threadIdx.x;
+    if (i >= cnt) return;
+    const uint32_t j = nn[i];
+    const bool mutual = j != i && nn[j] == i;
+    merge[i] = (mutual && i < j) ? 1u : 0u;
+    keep[i] = (mutual && i > j) ? 0u : 1u;
+}
+__global__ __launch_bounds__(256) void plocApplyKernel(const uint32_t* __restrict__ refIn, const float4* __restrict__ cminIn, const float4* __restrict__ cmaxIn,
+                                                       const uint32_t* __restrict__ nn, const uint32_t* __restrict__ merge, const uint32_t* __restrict__ keep,
+                                                       const uint32_t* __restrict__ mOff, const uint32_t* __restrict__ kOff, uint32_t cnt, uint32_t nodeBase,
+                                                       uint32_t n, uint32_t* __restrict__ refOut, float4* __restrict__ cminOut, float4* __restrict__ cmaxOut,
+                                                       uint2* __restrict__ children, uint32_t* __restrict__ totals) {
+    const uint32_t i = blockIdx.x * 256u + threadIdx.x;
+    if (i >= cnt) return;
+    if (i == cnt - 1u) { totals[0] = kOff[i] + keep[i]; totals[1] = mOff[i] + merge[i]; }
+    if (!keep[i]) return;
+    const uint32_t o = kOff[i];
+    float4 mn = cminIn[i], mx = cmaxIn[i];
+    uint32_t r = refIn[i];
+    if (merge[i]) {
+        const uint32_t j = nn[i];
+        const float4 bn = cminIn[j], bx = cmaxIn[j];
+        const uint32_t id = n - 2u - (nodeBase + mOff[i]);
+        children[id] = make_uint2(r, refIn[j]);
+        r = id;
+        mn = make_float4(fminf(mn.x, bn.x), fminf(mn.y, bn.y), fminf(mn.z, bn.z), 0.0f);
+        mx = make_float4(fmaxf(mx.x, bx.x), fmaxf(mx.y, bx.y), fmaxf(mx.z, bx.z), 0.0f);
+    }
+    refOut[o] = r; cminOut[o] = mn; cmaxOut[o] = mx;
+}
+
+// The same for small scenes (a rebuild per frame of the Pool's 4446 triangles): every round in ONE workgroup, so that a build is one launch
+// with no host round trips.  Thread t owns a contiguous run of the clusters; the runs' merge / keep counts are scanned in LDS.
+#define LRL_PLOC_SMALL_THREADS 1024
+__global__ __launch_bounds__(LRL_PLOC_SMALL_THREADS) void plocSmallKernel(const float4* __restrict__ pmin, const float4* __restrict__ pmax, const uint32_t* __restrict__ idx,
+                                                                          uint32_t n, uint32_t* refA, float4* minA, float4* maxA, uint32_t* refB, float4* minB,
+                                                                          float4* maxB, uint32_t* nn, uint2* children, uint32_t* parentInner, uint32_t* parentLeaf) {
+    __shared__ uint32_t sM[LRL_PLOC_SMALL_THREADS], sK[LRL_PLOC_SMALL_THREADS];
+    const uint32_t T = LRL_PLOC_SMALL_THREADS, tid = threadIdx.x;
+    for (uint32_t i = tid; i < n; i += T) {
+        const uint32_t p = idx[i];
+        refA[i] = LRL_REF_LEAF | i; minA[i] = pmin[p]; maxA[i] = pmax[p];
+    }
+    if (tid == 0) parentInner[0] = 0xffffffffu;
+    __syncthreads();
+    uint32_t cnt = n, nodeBase = 0;
+    while (cnt > 1u) {
+        const uint32_t chunk = (cnt + T - 1u) / T, lo = min(cnt, tid * chunk), hi = min(cnt, lo + chunk);
+        for (uint32_t i = lo; i < hi; ++i) {
+            const float4 mn = minA[i], mx = maxA[i];
+            float best = INFINITY;
+            uint32_t bestJ = i;
+            for (int d = 1; d <= LRL_PLOC_RADIUS; ++d)
+                for (int sgn = 0; sgn < 2; ++sgn) {
+                    const long long j = sgn ? (long long)i - d : (long long)i + d;
+                    if (j < 0 || j >= (long long)cnt) continue;
+                    const float a = unionArea(mn, mx, minA[j], maxA[j]);
+                    if (a < best || (a == best && uint32_t(j) == (i ^ 1u))) { best = a; bestJ = uint32_t(j); }
+                }
+            nn[i] = bestJ;
+        }
+        __syncthreads();
+        uint32_t m = 0, k = 0;
+        for (uint32_t i = lo; i < hi; ++i) {
+            const uint32_t j = nn[i];
+            const bool mutual = j != i && nn[j] == i;
+            m += (mutual && i < j) ? 1u : 0u;
+            k += (mutual && i > j) ? 0u : 1u;
+        }
+        sM[tid] = m; sK[tid] = k;
+        __syncthreads();
+        for (uint32_t off = 1; off < T; off <<= 1) {      // inclusive scans
+            const uint32_t am = tid >= off ? sM[tid - off] : 0u, ak = tid >= off ? sK[tid - off] : 0u;
+            __syncthreads();
+            sM[tid] += am; sK[tid] += ak;
+            __syncthreads();
+        }
+        uint32_t mo = sM[tid] - m, ko = sK[tid] - k;
+        const uint32_t merges = sM[T - 1u], keeps = sK[T - 1u];
+        for (uint32_t i = lo; i < hi; ++i) {
+            const uint32_t j = nn[i];
+            const bool mutual = j != i && nn[j] == i;
+            if (mutual && i > j) continue;
+            float4 mn = minA[i], mx = maxA[i];
+            uint32_t r = refA[i];
+            if (mutual) {
+                const float4 bn = minA[j], bx = maxA[j];
+                const uint32_t id = n - 2u - (nodeBase + mo++), rj = refA[j];
+                children[id] = make_uint2(r, rj);
+                if (r & LRL_REF_LEAF) parentLeaf[r & ~LRL_REF_LEAF] = id; else parentInner[r] = id;
+                if (rj & LRL_REF_LEAF) parentLeaf[rj & ~LRL_REF_LEAF] = id; else parentInner[rj] = id;
+                r = id;
+                mn = make_float4(fminf(mn.x, bn.x), fminf(mn.y, bn.y), fminf(mn.z, bn.z), 0.0f);
+                mx = make_float4(fmaxf(mx.x, bx.x), fmaxf(mx.y, bx.y), fmaxf(mx.z, bx.z), 0.0f);
+            }
+            refB[ko] = r; minB[ko] = mn; maxB[ko] = mx;
+            ++ko;
+        }
+        __syncthreads();
+        cnt = keeps; nodeBase += merges;
+        uint32_t* tr = refA; refA = refB; refB = tr;
+        float4* t4 = minA; minA = minB; minB = t4;
+        t4 = maxA; maxA = maxB; maxB = t4;
+    }
+}
+
 }  // namespace lrl_build
 
 hipError_t lrl_launch_triangle_boxes(const LrlTriangle* in, uint32_t first, uint32_t count, float4* pmin, float4* pmax, hipStream_t stream) {
@@ -395,13 +547,16 @@ size_t lrl_build_scratch_bytes(uint32_t n) {
     (void)rocprim::radix_sort_pairs(nullptr, sortTmp, k, k, v, v, size_t(n), 0, 63, hipStream_t(nullptr));
     const size_t N = n;
     // keys x2, idx x2, children, parents x2, counters, nodeMin, nodeMax, heights, h4, bounds + info
-    return sortTmp + N * (16 + 8 + 8 + 8 + 4 + 32 + 4 + 4) + 4096 + 16 * 256;
+    size_t scanTmp = 0;
+    (void)rocprim::exclusive_scan(nullptr, scanTmp, v, v, 0u, size_t(n), rocprim::plus<uint32_t>(), hipStream_t(nullptr));
+    // + PLOC: refs x2, boxes x2 x2, nearest, merge, keep, two offsets
+    return sortTmp + scanTmp + N * (16 + 8 + 8 + 8 + 4 + 32 + 4 + 4) + N * (8 + 64 + 20) + 4096 + 32 * 256;
 }
 
 // pmin / pmax: n primitive boxes (w of pmin = primitive bits).  recs / node4: n records each (n >= 2).  info (host-visible
 // after the stream is synchronised): {height of the binary tree, height of the four-wide tree}.
 hipError_t lrl_build_bvh(const float4* pmin, const float4* pmax, uint32_t n, float4* recs, uint4* node4, void* scratch, size_t scratchBytes,
-                         uint32_t* infoDev, hipStream_t stream) {
+                         uint32_t* infoDev, bool ploc, hipStream_t stream) {
     if (n < 2) return hipErrorInvalidValue;
     char* p = static_cast<char*>(scratch);
     auto take = [&](size_t bytes) { char* o = p; p += (bytes + 255) / 256 * 256; return o; };
@@ -433,6 +588,40 @@ hipError_t lrl_build_bvh(const float4* pmin, const float4* pmax, uint32_t n, flo
     hipLaunchKernelGGL(lrl_build::boundsKernel, dim3(std::min<uint32_t>(grd.x, 4096u)), blk, 0, stream, pmin, pmax, n, bounds);
     hipLaunchKernelGGL(lrl_build::mortonKernel, grd, blk, 0, stream, pmin, pmax, n, bounds, keysA, idxA);
     if ((e = rocprim::radix_sort_pairs(sortBuf, sortTmp, keysA, keysB, idxA, idxB, N, 0, 63, stream)) != hipSuccess) return e;
+    if (ploc) {
+        uint32_t* refA = reinterpret_cast<uint32_t*>(take(N * 4)); uint32_t* refB = reinterpret_cast<uint32_t*>(take(N * 4));
+        float4* minA = reinterpret_cast<float4*>(take(N * 16)); float4* minB = reinterpret_cast<float4*>(take(N * 16));
+        float4* maxA = reinterpret_cast<float4*>(take(N * 16)); float4* maxB = reinterpret_cast<float4*>(take(N * 16));
+        uint32_t* nn = reinterpret_cast<uint32_t*>(take(N * 4));
+        uint32_t* merge = reinterpret_cast<uint32_t*>(take(N * 4)); uint32_t* keep = reinterpret_cast<uint32_t*>(take(N * 4));
+        uint32_t* mOff = reinterpret_cast<uint32_t*>(take(N * 4)); uint32_t* kOff = reinterpret_cast<uint32_t*>(take(N * 4));
+        uint32_t* totals = reinterpret_cast<uint32_t*>(take(256));
+        size_t scanTmp = 0;
+        if ((e = rocprim::exclusive_scan(nullptr, scanTmp, merge, mOff, 0u, N, rocprim::plus<uint32_t>(), stream)) != hipSuccess) return e;
+        void* scanBuf = take(scanTmp);
+        if (size_t(p - static_cast<char*>(scratch)) > scratchBytes) return hipErrorOutOfMemory;
+        const bool small = n < LRL_BUILD_LEVELS_FROM;
+        if (small) hipLaunchKernelGGL(lrl_build::plocSmallKernel, dim3(1), dim3(LRL_PLOC_SMALL_THREADS), 0, stream, pmin, pmax, idxB, n, refA, minA, maxA, refB, minB, maxB,
+                                      nn, children, parentInner, parentLeaf);
+        else hipLaunchKernelGGL(lrl_build::plocInitKernel, grd, blk, 0, stream, pmin, pmax, idxB, n, refA, minA, maxA);
+        uint32_t cnt = small ? 1u : n, nodeBase = 0, rounds = 0;
+        while (cnt > 1u) {
+            if (++rounds > 4096u) return hipErrorUnknown;
+            const dim3 g((cnt + 255u) / 256u);
+            hipLaunchKernelGGL(lrl_build::plocNearestKernel, g, blk, 0, stream, minA, maxA, cnt, nn);
+            hipLaunchKernelGGL(lrl_build::plocMarkKernel, g, blk, 0, stream, nn, cnt, merge, keep);
+            if ((e = rocprim::exclusive_scan(scanBuf, scanTmp, merge, mOff, 0u, size_t(cnt), rocprim::plus<uint32_t>(), stream)) != hipSuccess) return e;
+            if ((e = rocprim::exclusive_scan(scanBuf, scanTmp, keep, kOff, 0u, size_t(cnt), rocprim::plus<uint32_t>(), stream)) != hipSuccess) return e;
+            hipLaunchKernelGGL(lrl_build::plocApplyKernel, g, blk, 0, stream, refA, minA, maxA, nn, merge, keep, mOff, kOff, cnt, nodeBase, n, refB, minB, maxB,
+                               children, totals);
+            uint32_t tot[2] = {0, 0};
+            if ((e = hipMemcpyAsync(tot, totals, 8, hipMemcpyDeviceToHost, stream)) != hipSuccess) return e;
+            if ((e = hipStreamSynchronize(stream)) != hipSuccess) return e;
+            if (tot[1] == 0u || tot[0] + tot[1] != cnt) return hipErrorUnknown;
+            cnt = tot[0]; nodeBase += tot[1];
+            std::swap(refA, refB); std::swap(minA, minB); std::swap(maxA, maxB);
+        }
+    } else
     hipLaunchKernelGGL(lrl_build::treeKernel, grd, blk, 0, stream, keysB, n, children, parentInner, parentLeaf);
     const bool byLevels = n >= LRL_BUILD_LEVELS_FROM;
     if (!byLevels) {

@@ -596,7 +596,8 @@ int runDeviceBuild(LrlContext* c, uint32_t prims, uint32_t& recCount, uint32_t& 
     if ((rc = ensure(c, c->buildScratch, buildBytes))) return rc;
     if ((rc = ensure(c, c->buildInfo, 256))) return rc;
     HIP_TRY(c, lrl_build_bvh(static_cast<const float4*>(c->primMin.p), static_cast<const float4*>(c->primMax.p), prims, static_cast<float4*>(c->nodes.p),
-                             static_cast<uint4*>(c->nodes32.p), c->buildScratch.p, buildBytes, static_cast<uint32_t*>(c->buildInfo.p), c->stream));
+                             static_cast<uint4*>(c->nodes32.p), c->buildScratch.p, buildBytes, static_cast<uint32_t*>(c->buildInfo.p),
+                             c->tuning.deviceBuilder ? c->tuning.deviceBuilder == 2u : prims >= LRL_BUILD_PLOC_FROM, c->stream));
     uint32_t info[2] = {0, 0};
     HIP_TRY(c, hipMemcpyAsync(info, c->buildInfo.p, 8, hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(c, hipStreamSynchronize(c->stream));
@@ -632,7 +633,7 @@ hipError_t noallocScratchFor(int device, void** out) {
 LrlTuning defaultTuning() {
     LrlTuning t{};
     t.handoverEarly = LRL_HANDOVER_AUTO; t.handoverLate = LRL_HANDOVER_AUTO; t.handoverListLen = 0;
-    t.adapt = 1; t.groupLanes = 0; t.contSlots = 0; t.groupCapX = 0; t.sparseFrom = 5; t.compactFrom = -1; t.coopFetch = 0; t.groupQuad = 0; t.streamWords = 0; t.refillMin = 16; t.phasedTrips = 0;
+    t.adapt = 1; t.groupLanes = 0; t.contSlots = 0; t.groupCapX = 0; t.sparseFrom = 5; t.compactFrom = -1; t.coopFetch = 0; t.groupQuad = 0; t.streamWords = 0; t.refillMin = 16; t.phasedTrips = 0; t.deviceBuilder = 0;
     t.workLow = 12.0f; t.pollLag = 1; t.traceRef = 0; t.batchSlots = 0; t.debug = 0;
     return t;
 }
@@ -714,6 +715,7 @@ int lrl_set_tuning(LrlContext* c, const LrlTuning* t) {
     if (t->contSlots > (1u << 22)) return fail(c, LRL_ERR_LIMIT, "contSlots > 2^22");
     if (t->coopFetch > 1 || t->groupQuad > 1) return fail(c, LRL_ERR_INVALID_ARG, "coopFetch and groupQuad must be 0 or 1");
     if (t->phasedTrips > 2) return fail(c, LRL_ERR_INVALID_ARG, "phasedTrips must be 0 (by launch size), 1 (on) or 2 (off)");
+    if (t->deviceBuilder > 2) return fail(c, LRL_ERR_INVALID_ARG, "deviceBuilder must be 0 (by size), 1 (LBVH) or 2 (PLOC)");
     if (t->streamWords > 4096 || t->refillMin > 64) return fail(c, LRL_ERR_INVALID_ARG, "streamWords <= 4096, refillMin <= 64");
     c->tuning = *t;
     c->phasedTrial.state = 0; c->phasedTrial.signature = 0;

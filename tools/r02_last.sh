@@ -14,3 +14,5 @@ run c4_1gpu --workload c4 --no-cpu-baseline
 run c5 --workload c5 --no-cpu-baseline
 run c2_device --builder device --no-c5 --no-cpu-baseline
 run c2_sah --builder sah --no-c5 --no-cpu-baseline
+run c3_device --workload c3 --builder device --no-cpu-baseline
+run c3_device_ploc --workload c3 --builder device --tuning deviceBuilder=2 --no-cpu-baseline
