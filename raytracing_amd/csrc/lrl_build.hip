@@ -413,7 +413,7 @@ __global__ __launch_bounds__(256) void plocNearestKernel(const float4* __restric
     const int li = i - base;
     const float4 mn = smin[li], mx = smax[li];
     float best = INFINITY;
-    int bestJ = i;
+    int bestJ = (i ^ 1) < int(cnt) ? (i ^ 1) : i - 1;      // (boxes with a NaN compare with nothing: they pair off with their buddies in the end)
     // nearest places first, so that among equal boxes the nearer neighbour wins; the buddy i ^ 1 wins every tie (a run of identical boxes
     // pairs off in one round instead of forming a chain that merges one pair a round)
     for (int d = 1; d <= RAD; ++d)
@@ -477,7 +477,7 @@ __global__ __launch_bounds__(LRL_PLOC_SMALL_THREADS) void plocSmallKernel(const 
         for (uint32_t i = lo; i < hi; ++i) {
             const float4 mn = minA[i], mx = maxA[i];
             float best = INFINITY;
-            uint32_t bestJ = i;
+            uint32_t bestJ = (i ^ 1u) < cnt ? (i ^ 1u) : i - 1u;
             for (int d = 1; d <= LRL_PLOC_RADIUS; ++d)
                 for (int sgn = 0; sgn < 2; ++sgn) {
                     const long long j = sgn ? (long long)i - d : (long long)i + d;

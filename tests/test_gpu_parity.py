@@ -787,6 +787,40 @@ def test_device_built_bvh_counts_and_edge_cases(tracer, default_model):
             check_image(im, imgs[0], abi.MODE_FAST, ("one / two primitives", nprim))
 
 
+@pytest.mark.parametrize("count", [1000, 70000])
+def test_device_builders_on_coincident_triangles(count):
+    """Thousands of identical triangles (equal Morton codes, equal boxes: every merge is a tie) and a few others: both builders finish (PLOC
+    pairs buddies off, in one workgroup below 65 536 primitives and in rounds of kernels above) and the frames agree: the nearest of equal
+    hits is decided by the primitive code, whatever the tree."""
+    from raytracing_amd import tracer as T
+    m = host.HostModel()
+    tri = np.zeros(count + 2, dtype=abi.TRIANGLE)
+    tri["p1"][:count] = (-1, -1, -5); tri["p2"][:count] = (1, -1, -5); tri["p3"][:count] = (0, 1, -5)
+    tri["p1"][count:] = [(-3, -1, -6), (2, -1, -4)]; tri["p2"][count:] = [(-1.5, -1, -6), (3.5, -1, -4)]; tri["p3"][count:] = [(-2, 1, -6), (3, 1, -4)]
+    tri["color"]["g"] = (0.25, 0.5, 0.75)
+    tri["color"]["g"][count:] = (0.75, 0.5, 0.25)
+    for f in ("texR", "texT", "texD", "texG"):
+        tri["color"][f] = -1
+    tri["color"]["n"] = 1.0
+    m.add_triangles(tri)
+    m.data_init("median")
+    trans = m.camera(64)
+    out = {}
+    for builder in (1, 2):
+        t = T.Tracer(0)
+        try:
+            t.set_tuning(deviceBuilder=builder)
+            t.scene_upload(without_tree(m))
+            t.set_camera(trans, 96, 64)
+            t.set_decay_origin((0, 0, 0, 1))
+            out[builder] = t.render(max_depth=2, mode=abi.MODE_FAST)
+        finally:
+            t.close()
+    assert (out[1][1][..., 0] == 2).sum() > 10                                    # the triangles are in view
+    assert np.array_equal(out[1][1], out[2][1]) and np.array_equal(out[1][0].view(np.uint32), out[2][0].view(np.uint32))
+    assert set(np.unique(out[2][1][..., 1][out[2][1][..., 0] == 2])) <= {0, count, count + 1}      # of the coincident ones, the lowest code
+
+
 def test_rebuild_of_a_device_built_tree_follows_the_water(tracer, pool_model):
     """Device-built tree over the Pool scene: after lrl_water_step the triangles have left the boxes the tree was built
     with; lrl_scene_rebuild_bvh builds it again from the current triangles and the image is the oracle's image of the moved
