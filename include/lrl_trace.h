@@ -171,10 +171,10 @@ typedef struct LrlTuning {
     uint32_t phasedTrips;        /* triangle trips of the lean kernel: a trip on which many lanes hold a triangle runs the triangle block alone and the  */
                                  /*   node lanes wait with their record (same frame bit for bit; faster on flat trees and incoherent rays, slower on     */
                                  /*   coherent ones): 1 on, 2 off, 0 = the library times one frame each way per scene and frame shape and keeps the faster */
-    uint32_t deviceBuilder;      /* the library's own tree (lrl_scene_upload without a tree, lrl_scene_rebuild_bvh): 1 = binary radix tree over    */
-                                 /*   Morton codes (LBVH), 2 = clusters merged with their nearest neighbour in Morton order (PLOC: the build takes    */
-                                 /*   three times as long, 0.7 ms for the Pool, and rays visit a fifth fewer nodes: C5 -5 %, the Pool -10 %),          */
-                                 /*   0 = PLOC from 65 536 primitives on, LBVH below (scenes small enough to be rebuilt every frame)                    */
+    uint32_t deviceBuilder;      /* the library's own tree (lrl_scene_upload without a tree, lrl_scene_rebuild_bvh): 0 / 2 = clusters merged with   */
+                                 /*   their nearest neighbour in Morton order (PLOC); 1 = binary radix tree over the Morton codes (LBVH): half the   */
+                                 /*   build time (0.23 against 0.48 ms for the Pool) for frames 5-10 % slower, the better choice only for a small      */
+                                 /*   scene that is rebuilt for every one- or two-sample frame                                                         */
     uint32_t debug;              /* 1: per-frame diagnostics on stderr (adds host waits); 2: a line around every HIP call of the   */
                                  /*   render path instead (no added waits); 3: both                                                */
 } LrlTuning;

@@ -385,7 +385,7 @@ __global__ __launch_bounds__(256) void fitLevelKernel(const float4* __restrict__
 // Every cluster looks LRL_PLOC_RADIUS places to either side for the neighbour with which it would make the smallest box; pairs that chose
 // each other merge into a new inner node, the rest wait; the survivors are compacted and the round repeats until one cluster is left.
 // Inner nodes are numbered from the root down (root = 0, as the fit kernels expect): the t-th merge of the build is node n - 2 - t.
-#define LRL_PLOC_RADIUS 16      /* (8, 32 and 64 give the same frame times within 1 %) */
+#define LRL_PLOC_RADIUS 8       /* (16, 32 and 64 give the same frame times within 1 %, and longer builds) */
 DI float unionArea(const float4& amin, const float4& amax, const float4& bmin, const float4& bmax) {
     const float dx = fmaxf(amax.x, bmax.x) - fminf(amin.x, bmin.x), dy = fmaxf(amax.y, bmax.y) - fminf(amin.y, bmin.y),
                 dz = fmaxf(amax.z, bmax.z) - fminf(amin.z, bmin.z);
@@ -463,8 +463,8 @@ __global__ __launch_bounds__(256) void plocApplyKernel(const uint32_t* __restric
 __global__ __launch_bounds__(LRL_PLOC_SMALL_THREADS) void plocSmallKernel(const float4* __restrict__ pmin, const float4* __restrict__ pmax, const uint32_t* __restrict__ idx,
                                                                           uint32_t n, uint32_t* refA, float4* minA, float4* maxA, uint32_t* refB, float4* minB,
                                                                           float4* maxB, uint32_t* nn, uint2* children, uint32_t* parentInner, uint32_t* parentLeaf) {
-    __shared__ uint32_t sM[LRL_PLOC_SMALL_THREADS], sK[LRL_PLOC_SMALL_THREADS];
-    const uint32_t T = LRL_PLOC_SMALL_THREADS, tid = threadIdx.x;
+    __shared__ uint32_t sM[LRL_PLOC_SMALL_THREADS / 64], sK[LRL_PLOC_SMALL_THREADS / 64];
+    const uint32_t T = LRL_PLOC_SMALL_THREADS, tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
     for (uint32_t i = tid; i < n; i += T) {
         const uint32_t p = idx[i];
         refA[i] = LRL_REF_LEAF | i; minA[i] = pmin[p]; maxA[i] = pmax[p];
@@ -473,7 +473,7 @@ __global__ __launch_bounds__(LRL_PLOC_SMALL_THREADS) void plocSmallKernel(const 
     __syncthreads();
     uint32_t cnt = n, nodeBase = 0;
     while (cnt > 1u) {
-        const uint32_t chunk = (cnt + T - 1u) / T, lo = min(cnt, tid * chunk), hi = min(cnt, lo + chunk);
+        const uint32_t chunk = (cnt + T - 1u) / T, lo = min(cnt, tid * chunk), hi = min(cnt, lo + chunk);      // chunk <= 64
         for (uint32_t i = lo; i < hi; ++i) {
             const float4 mn = minA[i], mx = maxA[i];
             float best = INFINITY;
@@ -488,30 +488,35 @@ __global__ __launch_bounds__(LRL_PLOC_SMALL_THREADS) void plocSmallKernel(const 
             nn[i] = bestJ;
         }
         __syncthreads();
-        uint32_t m = 0, k = 0;
+        // which of my clusters merge (the lower of a mutual pair) and which go (the upper): one bit each
+        unsigned long long mergeBits = 0ull, goneBits = 0ull;
         for (uint32_t i = lo; i < hi; ++i) {
             const uint32_t j = nn[i];
             const bool mutual = j != i && nn[j] == i;
-            m += (mutual && i < j) ? 1u : 0u;
-            k += (mutual && i > j) ? 0u : 1u;
+            if (mutual && i < j) mergeBits |= 1ull << (i - lo);
+            if (mutual && i > j) goneBits |= 1ull << (i - lo);
         }
-        sM[tid] = m; sK[tid] = k;
+        const uint32_t m = uint32_t(__popcll(mergeBits)), k = (hi - lo) - uint32_t(__popcll(goneBits));
+        // exclusive scans over the threads: within the wave by shuffles, across the sixteen waves through LDS
+        uint32_t im = m, ik = k;
+        for (int off = 1; off < 64; off <<= 1) {
+            const uint32_t am = uint32_t(__shfl_up(int(im), off, 64)), ak = uint32_t(__shfl_up(int(ik), off, 64));
+            if (lane >= uint32_t(off)) { im += am; ik += ak; }
+        }
+        if (lane == 63u) { sM[wave] = im; sK[wave] = ik; }
         __syncthreads();
-        for (uint32_t off = 1; off < T; off <<= 1) {      // inclusive scans
-            const uint32_t am = tid >= off ? sM[tid - off] : 0u, ak = tid >= off ? sK[tid - off] : 0u;
-            __syncthreads();
-            sM[tid] += am; sK[tid] += ak;
-            __syncthreads();
+        uint32_t mo = im - m, ko = ik - k, merges = 0, keeps = 0;
+        for (uint32_t w = 0; w < T / 64u; ++w) {
+            const uint32_t wm = sM[w], wk = sK[w];
+            if (w < wave) { mo += wm; ko += wk; }
+            merges += wm; keeps += wk;
         }
-        uint32_t mo = sM[tid] - m, ko = sK[tid] - k;
-        const uint32_t merges = sM[T - 1u], keeps = sK[T - 1u];
         for (uint32_t i = lo; i < hi; ++i) {
-            const uint32_t j = nn[i];
-            const bool mutual = j != i && nn[j] == i;
-            if (mutual && i > j) continue;
+            if ((goneBits >> (i - lo)) & 1ull) continue;
             float4 mn = minA[i], mx = maxA[i];
             uint32_t r = refA[i];
-            if (mutual) {
+            if ((mergeBits >> (i - lo)) & 1ull) {
+                const uint32_t j = nn[i];
                 const float4 bn = minA[j], bx = maxA[j];
                 const uint32_t id = n - 2u - (nodeBase + mo++), rj = refA[j];
                 children[id] = make_uint2(r, rj);

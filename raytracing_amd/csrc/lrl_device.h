@@ -216,7 +216,6 @@ hipError_t lrl_launch_circle_pre(LrlCircle* circles, uint32_t count, hipStream_t
 // the min corner = primitive bits; writes n records into recs and node4, {height, four-wide height} into info)
 hipError_t lrl_launch_triangle_boxes(const LrlTriangle* in, uint32_t first, uint32_t count, float4* pmin, float4* pmax, hipStream_t stream);
 size_t lrl_build_scratch_bytes(uint32_t n);
-#define LRL_BUILD_PLOC_FROM (1u << 16)      /* LrlTuning.deviceBuilder = 0: PLOC from this many primitives on */
 hipError_t lrl_build_bvh(const float4* pmin, const float4* pmax, uint32_t n, float4* recs, uint4* node4, void* scratch, size_t scratchBytes,
                          uint32_t* infoDev, bool ploc, hipStream_t stream);
 hipError_t lrl_launch_quantize(const float4* in, uchar4* out, unsigned long long pixels, hipStream_t stream);   // RGBA32F -> RGBA8 (unorm)

@@ -597,7 +597,7 @@ int runDeviceBuild(LrlContext* c, uint32_t prims, uint32_t& recCount, uint32_t& 
     if ((rc = ensure(c, c->buildInfo, 256))) return rc;
     HIP_TRY(c, lrl_build_bvh(static_cast<const float4*>(c->primMin.p), static_cast<const float4*>(c->primMax.p), prims, static_cast<float4*>(c->nodes.p),
                              static_cast<uint4*>(c->nodes32.p), c->buildScratch.p, buildBytes, static_cast<uint32_t*>(c->buildInfo.p),
-                             c->tuning.deviceBuilder ? c->tuning.deviceBuilder == 2u : prims >= LRL_BUILD_PLOC_FROM, c->stream));
+                             c->tuning.deviceBuilder != 1u, c->stream));
     uint32_t info[2] = {0, 0};
     HIP_TRY(c, hipMemcpyAsync(info, c->buildInfo.p, 8, hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(c, hipStreamSynchronize(c->stream));
@@ -715,7 +715,7 @@ int lrl_set_tuning(LrlContext* c, const LrlTuning* t) {
     if (t->contSlots > (1u << 22)) return fail(c, LRL_ERR_LIMIT, "contSlots > 2^22");
     if (t->coopFetch > 1 || t->groupQuad > 1) return fail(c, LRL_ERR_INVALID_ARG, "coopFetch and groupQuad must be 0 or 1");
     if (t->phasedTrips > 2) return fail(c, LRL_ERR_INVALID_ARG, "phasedTrips must be 0 (by launch size), 1 (on) or 2 (off)");
-    if (t->deviceBuilder > 2) return fail(c, LRL_ERR_INVALID_ARG, "deviceBuilder must be 0 (by size), 1 (LBVH) or 2 (PLOC)");
+    if (t->deviceBuilder > 2) return fail(c, LRL_ERR_INVALID_ARG, "deviceBuilder must be 0 (PLOC), 1 (LBVH) or 2 (PLOC)");
     if (t->streamWords > 4096 || t->refillMin > 64) return fail(c, LRL_ERR_INVALID_ARG, "streamWords <= 4096, refillMin <= 64");
     c->tuning = *t;
     c->phasedTrial.state = 0; c->phasedTrial.signature = 0;

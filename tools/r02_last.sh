@@ -15,4 +15,4 @@ run c5 --workload c5 --no-cpu-baseline
 run c2_device --builder device --no-c5 --no-cpu-baseline
 run c2_sah --builder sah --no-c5 --no-cpu-baseline
 run c3_device --workload c3 --builder device --no-cpu-baseline
-run c3_device_ploc --workload c3 --builder device --tuning deviceBuilder=2 --no-cpu-baseline
+run c3_device_lbvh --workload c3 --builder device --tuning deviceBuilder=1 --no-cpu-baseline
