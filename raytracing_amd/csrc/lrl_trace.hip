@@ -72,6 +72,8 @@ struct LrlContext {
     uint32_t parkedTight = 0;     // triangles that nodes32 bounds by their own boxes (fitOwnBoxes)
     bool haveLoose = false;       // nodes32Loose holds the same four-wide tree with the caller's boxes only
     bool looseInUse = false;      // primitives changed under the caller's tree since it came: its boxes alone are the contract (ownBoxesStale)
+    std::vector<LrlBVHNode> callerTree;   // the caller's tree, kept where fitting pays: a scene that has come to rest is fitted again (refitAtRest)
+    uint64_t samplesAtRest = 0;   // samples rendered since the last change under the caller's tree
 
     // frame
     LrlTrans trans{};
@@ -462,6 +464,7 @@ bool ownTriangleBoxes(LrlContext* c, uint32_t first, uint32_t count, const LrlTr
 // were made tall enough for every wave, Pool/Pool.cpp:250-263), until the next tree arrives.
 void ownBoxesStale(LrlContext* c) {
     if (c->haveLoose) c->looseInUse = true;
+    c->samplesAtRest = 0;
 }
 
 // TrianglePre for [first, first+count): materials interned on the host, geometry on the device.
@@ -805,12 +808,50 @@ static int uploadCallerTree(LrlContext* c, const LrlSceneView* s, uint32_t& recC
     c->parkedTight = uint32_t(tightened);
     if (fit) {      // the same tree with the caller's boxes, for when the primitives move under it (ownBoxesStale)
         node4 = buildNode4(s, nullptr, recOf, recCount, depth4);
+        c->node4Depth = std::max(c->node4Depth, depth4);      // (the stacks are sized for either copy)
         rc = upload(c, c->nodes32Loose, node4.data(), node4.size() * sizeof(uint4));
         if (rc) return rc;
         HIP_TRY(c, hipStreamSynchronize(c->stream));
         c->haveLoose = true;
-    }
+        if (c->callerTree.data() != s->bvh) c->callerTree.assign(s->bvh, s->bvh + s->bvhNodeNum);
+    } else if (c->callerTree.data() != s->bvh) { c->callerTree.clear(); c->callerTree.shrink_to_fit(); }
+    c->samplesAtRest = 0;
     if (c->tuning.debug) std::fprintf(stderr, "lrl: the four-wide tree bounds %zu primitives by their own boxes\n", tightened);
+    return LRL_OK;
+}
+
+// A scene whose triangles moved under the caller's tree and have come to rest (eight samples rendered without a change: the paused Pool
+// after the init-time sync of its water, Pool/Pool.cpp:648-650; a loop that moves the water every few one-sample frames never gets here)
+// is fitted again: the water's triangles, which moved on the device, are read back for
+// their boxes (the others' are kept current by the update calls), and the fitted copy of the four-wide tree is made anew.  Renders in flight
+// walk the other copy.
+static int refitAtRest(LrlContext* c, uint32_t samples) {
+    if (!c->looseInUse || c->callerTree.empty() || c->deviceBuilt) return LRL_OK;
+    if (c->samplesAtRest < 8) { c->samplesAtRest += samples; return LRL_OK; }
+    if (c->waterGX && c->ownBox.size() >= size_t(c->num.triangleNum) * 6) {
+        const uint32_t count = 2u * (c->waterGX - 1) * (c->waterGY - 1);
+        std::vector<LrlTriangle> t(count);
+        HIP_TRY(c, hipStreamSynchronize(c->stream));
+        HIP_TRY(c, hipMemcpy(t.data(), c->waterTris.p, size_t(count) * sizeof(LrlTriangle), hipMemcpyDeviceToHost));
+        (void)ownTriangleBoxes(c, c->waterFirst, count, t.data());
+    }
+    LrlSceneView v{};
+    v.num = c->num; v.bvh = c->callerTree.data(); v.bvhNodeNum = uint32_t(c->callerTree.size());
+    uint32_t recCount = 1;
+    std::vector<uint32_t> recOf(v.bvhNodeNum, 0);
+    for (uint32_t i = 0; i < v.bvhNodeNum; ++i) if (v.bvh[i].bound.leftChild) recOf[i] = recCount++;
+    FittedBoxes fitted;
+    if (!fitOwnBoxes(&v, c->ownBox, fitted)) { c->samplesAtRest = 0; c->callerTree.clear(); c->callerTree.shrink_to_fit(); return LRL_OK; }      // (nothing to gain any more)
+    uint32_t depth4 = 0;
+    std::vector<uint4> node4 = buildNode4(&v, &fitted, recOf, recCount, depth4);
+    int rc = upload(c, c->nodes32, node4.data(), node4.size() * sizeof(uint4));
+    if (rc) return rc;
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    c->node4Depth = std::max(c->node4Depth, depth4);
+    c->parkedTight = uint32_t(fitted.count);
+    c->looseInUse = false;
+    c->samplesAtRest = 0;
+    if (c->tuning.debug) std::fprintf(stderr, "lrl: the scene is at rest: the four-wide tree is fitted again (%zu own boxes)\n", fitted.count);
     return LRL_OK;
 }
 
@@ -843,6 +884,7 @@ int lrl_scene_upload(LrlContext* c, const LrlSceneView* s) {
     // nodes: the reference's 64-B own-box records -> 64-B inner records that hold both children's boxes
     uint32_t recCount = 1;
     c->ownBox.clear(); c->ownBox.shrink_to_fit();
+    if (deviceBuild) { c->callerTree.clear(); c->callerTree.shrink_to_fit(); }
     c->haveLoose = c->looseInUse = false;
     c->parkedTight = 0;
     if (!deviceBuild) {
@@ -1468,6 +1510,7 @@ static int renderImpl(LrlContext* c, const LrlRenderParams* p, float* rgbaDev, u
     const uint32_t spp = p->spp;
     uint32_t s0 = p->sampleBegin, s1 = p->sampleEnd;
     if (s0 == 0 && s1 == 0) s1 = spp;
+    if (int rcFit = refitAtRest(c, s1 - s0)) return rcFit;
     // per-sample camera: the jitter is the shear of `trans`; computed here in float like the host helper
     std::vector<LrlTrans> tr(spp, c->trans);
     if (p->jitter) {

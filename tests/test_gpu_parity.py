@@ -1101,6 +1101,48 @@ def test_parked_primitives_are_bounded_by_their_own_boxes(tracer, pool_model):
     assert np.array_equal(a[1], c[1]) and np.array_equal(a[0].view(np.uint32), c[0].view(np.uint32))
 
 
+def test_a_scene_at_rest_is_fitted_again(pool_model):
+    """The Pool's binding syncs the water's triangles on the device once at start-up (lrl_water_init + lrl_water_step(0),
+    Pool/Pool.cpp:648-650): they have moved under the caller's tree, so its boxes alone decide.  Once eight samples have been rendered with
+    nothing moving, the library reads the water's triangles back, fits the four-wide tree to where they are now and goes on with that:
+    the same frames bit for bit, before and after, at rest and after real waves (checked against the oracle on the moved triangles)."""
+    from raytracing_amd import tracer as T
+    gx, gy = scenes.POOL_GRID
+    k, dt = scenes.POOL_WATER
+    nw = 2 * (gx - 1) * (gy - 1)
+    tris = pool_model.arrays()["triangles"]
+    w0 = scenes.pool_water_points(pool_model)
+    g = load_golden("pool_viewB_192")
+    W, H = g["width"], g["height"]
+    kw = dict(max_depth=8, variant=abi.VARIANT_POOL, mode=abi.MODE_FAST)
+    t = T.Tracer(0)
+    try:
+        t.scene_upload(pool_model.scene_view())
+        t.set_camera(g["trans"], W, H)
+        t.set_decay_origin((0, 0, 0, 1))
+        fitted = t.scene_info()["ownBoxes"]
+        assert fitted > 2000
+        t.water_init(gx, gy, k, dt, w0, 0, tris[:nw])
+        for steps in (0, 200):
+            t.water_step(steps)
+            assert t.scene_info()["ownBoxes"] == 0
+            first = t.render(**kw)
+            for i in range(8):
+                assert t.scene_info()["ownBoxes"] == 0, i
+                again = t.render(**kw)
+                assert np.array_equal(again[1], first[1]) and np.array_equal(again[0].view(np.uint32), first[0].view(np.uint32)), (steps, i)
+            assert t.scene_info()["ownBoxes"] >= fitted - 50                     # (fitted again on the ninth render)
+            again = t.render(**kw)
+            assert np.array_equal(again[0].view(np.uint32), first[0].view(np.uint32))
+            ow = O.water_run(w0, gx, gy, k, dt, steps) if steps else w0
+            ot = O.water_sync(ow, gx, gy, tris)
+            oimg, ohits, _ = O.render(view_with(pool_model, ot), g["trans"], W, H, max_depth=8, variant=abi.VARIANT_POOL, threads=8)
+            assert (again[1] == ohits).all(axis=-1).mean() >= 0.9995
+            check_image(again[0], oimg, abi.MODE_FAST, ("the Pool fitted again at rest", steps))
+    finally:
+        t.close()
+
+
 def test_scene_changes_and_renders_on_a_callers_stream_are_ordered(pool_model):
     """lrl_water_step only queues its kernels on the context's stream, and lrl_render_async may run on a stream of the caller's: a render
     must see the water step queued before it, and the next water step (or triangle update) must not overwrite triangles the render in

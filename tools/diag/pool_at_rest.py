@@ -1,0 +1,32 @@
+"""The Pool's binding flow (scene upload, lrl_water_init, lrl_water_step(0), then 64-spp frames): frame times before and after the
+library fits the four-wide tree again (refitAtRest)."""
+import sys, os, time
+root = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, root)
+import torch
+from raytracing_amd import scenes, abi, host, tracer as T
+m = scenes.pool()
+W, H, spp = 1920, 1080, 64
+gx, gy = scenes.POOL_GRID
+k, dt = scenes.POOL_WATER
+tris = m.arrays()["triangles"]
+t = T.Tracer(0)
+t.scene_upload(m.scene_view()); t.set_camera(m.camera(H), W, H); t.set_decay_origin((0, 0, 0, 1))
+out = torch.zeros((H, W, 4), dtype=torch.float32, device="cuda:0")
+jit = host.jitter_table(spp)
+def frame():
+    torch.cuda.synchronize(); t0 = time.perf_counter()
+    t.render_device(out.data_ptr(), max_depth=8, variant=abi.VARIANT_POOL, mode=abi.MODE_FAST, jitter=jit)
+    t.sync(); return (time.perf_counter() - t0) * 1e3
+t.set_tuning(phasedTrips=1)
+for _ in range(4): frame()
+print("as uploaded      ", round(frame(), 2), "ms, own boxes", t.scene_info()["ownBoxes"])
+t.water_init(gx, gy, k, dt, scenes.pool_water_points(m), 0, tris[:2 * (gx - 1) * (gy - 1)])
+t.water_step(0)
+print("after the sync   ", round(frame(), 2), "ms, own boxes", t.scene_info()["ownBoxes"])
+print("next frame       ", round(frame(), 2), "ms (with the refit), own boxes", t.scene_info()["ownBoxes"])
+for _ in range(3): frame()
+print("at rest          ", round(frame(), 2), "ms, own boxes", t.scene_info()["ownBoxes"])
+for i in range(3):
+    t.water_step(200)
+    print("water moving     ", round(frame(), 2), "ms, own boxes", t.scene_info()["ownBoxes"])
