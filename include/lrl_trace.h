@@ -284,8 +284,8 @@ typedef struct LrlSceneInfo {
                                 whenever the ray enters the node; one whose leaf box was made larger than it is).  0 once a
                                 triangle has left the box it had when the tree came (update calls, water steps): then the
                                 caller's boxes alone decide, as the reference's do while the Pool's water moves under its fixed
-                                tree (Pool/Pool.cpp:250-263), until the next lrl_scene_update_bvh or until the scene has been at
-                                rest for eight rendered samples (the library then fits the tree again by itself).                */
+                                tree (Pool/Pool.cpp:250-263), until the next lrl_scene_update_bvh or until the rendering since the
+                                move is worth a new fit (2048 paths per node: the library then fits the tree again by itself).   */
 } LrlSceneInfo;
 int lrl_scene_info(const LrlContext* ctx, LrlSceneInfo* out);
 typedef struct LrlRenderInfo {       /* of the last wavefront-pipeline render */

@@ -73,7 +73,7 @@ struct LrlContext {
     bool haveLoose = false;       // nodes32Loose holds the same four-wide tree with the caller's boxes only
     bool looseInUse = false;      // primitives changed under the caller's tree since it came: its boxes alone are the contract (ownBoxesStale)
     std::vector<LrlBVHNode> callerTree;   // the caller's tree, kept where fitting pays: a scene that has come to rest is fitted again (refitAtRest)
-    uint64_t samplesAtRest = 0;   // samples rendered since the last change under the caller's tree
+    uint64_t pathsAtRest = 0;     // paths (pixels x samples) rendered since the last change under the caller's tree
 
     // frame
     LrlTrans trans{};
@@ -464,7 +464,7 @@ bool ownTriangleBoxes(LrlContext* c, uint32_t first, uint32_t count, const LrlTr
 // were made tall enough for every wave, Pool/Pool.cpp:250-263), until the next tree arrives.
 void ownBoxesStale(LrlContext* c) {
     if (c->haveLoose) c->looseInUse = true;
-    c->samplesAtRest = 0;
+    c->pathsAtRest = 0;
 }
 
 // TrianglePre for [first, first+count): materials interned on the host, geometry on the device.
@@ -815,19 +815,24 @@ static int uploadCallerTree(LrlContext* c, const LrlSceneView* s, uint32_t& recC
         c->haveLoose = true;
         if (c->callerTree.data() != s->bvh) c->callerTree.assign(s->bvh, s->bvh + s->bvhNodeNum);
     } else if (c->callerTree.data() != s->bvh) { c->callerTree.clear(); c->callerTree.shrink_to_fit(); }
-    c->samplesAtRest = 0;
+    c->pathsAtRest = 0;
     if (c->tuning.debug) std::fprintf(stderr, "lrl: the four-wide tree bounds %zu primitives by their own boxes\n", tightened);
     return LRL_OK;
 }
 
-// A scene whose triangles moved under the caller's tree and have come to rest (eight samples rendered without a change: the paused Pool
-// after the init-time sync of its water, Pool/Pool.cpp:648-650; a loop that moves the water every few one-sample frames never gets here)
-// is fitted again: the water's triangles, which moved on the device, are read back for
+// A scene whose triangles moved under the caller's tree is fitted again when the rendering since the move is worth it: the fit costs about
+// 0.2 us per node of the tree (on the host) and saves a third of a frame that costs about 0.5 ns per path, so it is done before the render
+// that takes the paths since the move past 2048 per node (the Pool: 13.7 M paths, seven samples of 1080p: the paused Pool a few frames after
+// the init-time sync of its water, Pool/Pool.cpp:648-650; a 64-sample frame right after a water step; never a loop of one-sample frames
+// with a step each): the water's triangles, which moved on the device, are read back for
 // their boxes (the others' are kept current by the update calls), and the fitted copy of the four-wide tree is made anew.  Renders in flight
 // walk the other copy.
-static int refitAtRest(LrlContext* c, uint32_t samples) {
+static int refitAtRest(LrlContext* c, uint64_t paths) {
     if (!c->looseInUse || c->callerTree.empty() || c->deviceBuilt) return LRL_OK;
-    if (c->samplesAtRest < 8) { c->samplesAtRest += samples; return LRL_OK; }
+    c->pathsAtRest += paths;
+    if (c->pathsAtRest < 2048ull * c->callerTree.size()) return LRL_OK;
+    if (int rc0 = orderAfterRenders(c)) return rc0;      // (a frame in flight on another stream may still walk the copy that is about to be replaced)
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
     if (c->waterGX && c->ownBox.size() >= size_t(c->num.triangleNum) * 6) {
         const uint32_t count = 2u * (c->waterGX - 1) * (c->waterGY - 1);
         std::vector<LrlTriangle> t(count);
@@ -841,7 +846,7 @@ static int refitAtRest(LrlContext* c, uint32_t samples) {
     std::vector<uint32_t> recOf(v.bvhNodeNum, 0);
     for (uint32_t i = 0; i < v.bvhNodeNum; ++i) if (v.bvh[i].bound.leftChild) recOf[i] = recCount++;
     FittedBoxes fitted;
-    if (!fitOwnBoxes(&v, c->ownBox, fitted)) { c->samplesAtRest = 0; c->callerTree.clear(); c->callerTree.shrink_to_fit(); return LRL_OK; }      // (nothing to gain any more)
+    if (!fitOwnBoxes(&v, c->ownBox, fitted)) { c->pathsAtRest = 0; c->callerTree.clear(); c->callerTree.shrink_to_fit(); return LRL_OK; }      // (nothing to gain any more)
     uint32_t depth4 = 0;
     std::vector<uint4> node4 = buildNode4(&v, &fitted, recOf, recCount, depth4);
     int rc = upload(c, c->nodes32, node4.data(), node4.size() * sizeof(uint4));
@@ -850,7 +855,7 @@ static int refitAtRest(LrlContext* c, uint32_t samples) {
     c->node4Depth = std::max(c->node4Depth, depth4);
     c->parkedTight = uint32_t(fitted.count);
     c->looseInUse = false;
-    c->samplesAtRest = 0;
+    c->pathsAtRest = 0;
     if (c->tuning.debug) std::fprintf(stderr, "lrl: the scene is at rest: the four-wide tree is fitted again (%zu own boxes)\n", fitted.count);
     return LRL_OK;
 }
@@ -1510,7 +1515,7 @@ static int renderImpl(LrlContext* c, const LrlRenderParams* p, float* rgbaDev, u
     const uint32_t spp = p->spp;
     uint32_t s0 = p->sampleBegin, s1 = p->sampleEnd;
     if (s0 == 0 && s1 == 0) s1 = spp;
-    if (int rcFit = refitAtRest(c, s1 - s0)) return rcFit;
+    if (int rcFit = refitAtRest(c, uint64_t(s1 - s0) * c->width * rows)) return rcFit;
     // per-sample camera: the jitter is the shear of `trans`; computed here in float like the host helper
     std::vector<LrlTrans> tr(spp, c->trans);
     if (p->jitter) {

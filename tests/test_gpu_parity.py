@@ -1101,20 +1101,30 @@ def test_parked_primitives_are_bounded_by_their_own_boxes(tracer, pool_model):
     assert np.array_equal(a[1], c[1]) and np.array_equal(a[0].view(np.uint32), c[0].view(np.uint32))
 
 
-def test_a_scene_at_rest_is_fitted_again(pool_model):
+def test_a_moved_scene_is_fitted_again_when_it_pays(pool_model):
     """The Pool's binding syncs the water's triangles on the device once at start-up (lrl_water_init + lrl_water_step(0),
-    Pool/Pool.cpp:648-650): they have moved under the caller's tree, so its boxes alone decide.  Once eight samples have been rendered with
-    nothing moving, the library reads the water's triangles back, fits the four-wide tree to where they are now and goes on with that:
-    the same frames bit for bit, before and after, at rest and after real waves (checked against the oracle on the moved triangles)."""
+    Pool/Pool.cpp:648-650): they have moved under the caller's tree, so its boxes alone decide.  Once the frames rendered since the move
+    are worth the fit (2048 paths per node of the tree), the library reads the water's triangles back, fits the four-wide tree to where
+    they are now and goes on with that: the same frames, before and after, at rest and after real waves (checked against the oracle on
+    the moved triangles).  A large frame right after a move is fitted at once.
+    "The same" is bit for bit except at floating-point tie edges: of this view's 36 864 x 64 primary rays one passes 8e-7 (barycentric) from
+    the edge shared by triangles 1120 and 1167; FAST arithmetic finds it inside both, 1167 an ulp nearer.  The caller's leaf box of 1167
+    ends exactly on that edge and the slab arithmetic's rounding turns the ray away, so the caller's boxes give 1120 (as the oracle does);
+    the fitted boxes have a margin and give 1167 (tools/diag/fit_diff2.py)."""
     from raytracing_amd import tracer as T
     gx, gy = scenes.POOL_GRID
     k, dt = scenes.POOL_WATER
     nw = 2 * (gx - 1) * (gy - 1)
     tris = pool_model.arrays()["triangles"]
+    nodes = len(pool_model.arrays()["bvh"])
     w0 = scenes.pool_water_points(pool_model)
     g = load_golden("pool_viewB_192")
-    W, H = g["width"], g["height"]
-    kw = dict(max_depth=8, variant=abi.VARIANT_POOL, mode=abi.MODE_FAST)
+    W, H, spp = g["width"], g["height"], 64
+    jit = host.jitter_table(spp)
+    kw = dict(max_depth=8, variant=abi.VARIANT_POOL, mode=abi.MODE_FAST, jitter=jit)
+    per_render = W * H * spp
+    need = -(-2048 * nodes // per_render)                     # renders until the fit pays
+    assert 3 <= need <= 12
     t = T.Tracer(0)
     try:
         t.scene_upload(pool_model.scene_view())
@@ -1125,20 +1135,26 @@ def test_a_scene_at_rest_is_fitted_again(pool_model):
         t.water_init(gx, gy, k, dt, w0, 0, tris[:nw])
         for steps in (0, 200):
             t.water_step(steps)
-            assert t.scene_info()["ownBoxes"] == 0
-            first = t.render(**kw)
-            for i in range(8):
-                assert t.scene_info()["ownBoxes"] == 0, i
+            first = None
+            for i in range(need + 1):
+                # the render that takes the paths since the move past the bar fits the tree first
+                assert (t.scene_info()["ownBoxes"] == 0) == (i < need), (steps, i)
                 again = t.render(**kw)
-                assert np.array_equal(again[1], first[1]) and np.array_equal(again[0].view(np.uint32), first[0].view(np.uint32)), (steps, i)
-            assert t.scene_info()["ownBoxes"] >= fitted - 50                     # (fitted again on the ninth render)
-            again = t.render(**kw)
-            assert np.array_equal(again[0].view(np.uint32), first[0].view(np.uint32))
+                first = first or again
+                moved = int((again[0].view(np.uint32) != first[0].view(np.uint32)).any(axis=-1).sum())
+                assert np.array_equal(again[1], first[1]) and moved <= (2 if i >= need - 1 else 0), (steps, i, moved)      # (render need - 1 is the first on the fitted tree)
+            assert t.scene_info()["ownBoxes"] >= fitted - 50
             ow = O.water_run(w0, gx, gy, k, dt, steps) if steps else w0
             ot = O.water_sync(ow, gx, gy, tris)
-            oimg, ohits, _ = O.render(view_with(pool_model, ot), g["trans"], W, H, max_depth=8, variant=abi.VARIANT_POOL, threads=8)
+            oimg, ohits, _ = O.render(view_with(pool_model, ot), host.sample_trans(g["trans"], jit), W, H, max_depth=8, variant=abi.VARIANT_POOL, threads=8)
             assert (again[1] == ohits).all(axis=-1).mean() >= 0.9995
-            check_image(again[0], oimg, abi.MODE_FAST, ("the Pool fitted again at rest", steps))
+            check_image(again[0], oimg, abi.MODE_FAST, ("the Pool fitted again", steps))
+        # a frame that is worth the fit by itself
+        t.water_step(50)
+        assert t.scene_info()["ownBoxes"] == 0
+        t.set_camera(g["trans"], 4 * W, 4 * H)
+        big = t.render(**kw)
+        assert t.scene_info()["ownBoxes"] >= fitted - 50
     finally:
         t.close()
 

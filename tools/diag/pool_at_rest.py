@@ -1,5 +1,5 @@
-"""The Pool's binding flow (scene upload, lrl_water_init, lrl_water_step(0), then 64-spp frames): frame times before and after the
-library fits the four-wide tree again (refitAtRest)."""
+"""The Pool's binding flow (scene upload, lrl_water_init, lrl_water_step(0), 64-spp frames, then 200 water substeps before every frame):
+frame times with the library fitting the four-wide tree again whenever that pays (refitAtRest)."""
 import sys, os, time
 root = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, root)
@@ -24,7 +24,7 @@ print("as uploaded      ", round(frame(), 2), "ms, own boxes", t.scene_info()["o
 t.water_init(gx, gy, k, dt, scenes.pool_water_points(m), 0, tris[:2 * (gx - 1) * (gy - 1)])
 t.water_step(0)
 print("after the sync   ", round(frame(), 2), "ms, own boxes", t.scene_info()["ownBoxes"])
-print("next frame       ", round(frame(), 2), "ms (with the refit), own boxes", t.scene_info()["ownBoxes"])
+print("next frame       ", round(frame(), 2), "ms, own boxes", t.scene_info()["ownBoxes"])
 for _ in range(3): frame()
 print("at rest          ", round(frame(), 2), "ms, own boxes", t.scene_info()["ownBoxes"])
 for i in range(3):
