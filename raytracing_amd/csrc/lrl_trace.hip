@@ -1344,6 +1344,8 @@ static int renderWavefront(LrlContext* c, const LrlRenderParams* p, const KScene
             const uint32_t served = std::min(asked, slotsThen);
             const float perRay = served ? 16.0f * float(work) / float(served) : 0.0f;       // one wave in 16 reports
             c->workPerRay[i] = perRay;
+            // a few dozen rays that were nearly done (the default scene: 20-90 rays an iteration with 2-5 entries each) are not worth a launch
+            if (served < 1024u && perRay < workLow) c->handoverIdle[i] = 1;
             // rays that were nearly done when they left (a few frontier entries each) cost more to hand over than to finish
             // where they were: Pool's rays are all of middling length; the mesh scenes' long rays need 30-40 entries
             if (!adapt) {}
