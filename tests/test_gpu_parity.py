@@ -1101,6 +1101,45 @@ def test_parked_primitives_are_bounded_by_their_own_boxes(tracer, pool_model):
     assert np.array_equal(a[1], c[1]) and np.array_equal(a[0].view(np.uint32), c[0].view(np.uint32))
 
 
+def test_oversized_boxes_of_a_callers_tree_are_fitted(tracer, bunny0_model):
+    """Any caller's tree whose boxes are larger than what they hold gains from the fit, not only the Pool's: the bunny's median-split tree
+    with every box grown by 4 % of the scene (still nested, still valid for the reference's traversal) renders the oracle's image of
+    that tree, the same hits as with the tight tree, and `ownBoxes` says every triangle is bounded by its own box; a tree that is not
+    nested (one leaf box poking out of its parent's) is walked with the caller's boxes as they are."""
+    m = bunny0_model
+    W, H = 160, 92                                  # (the oracle pays for the grown boxes: 10 s)
+    tr = m.camera(H)
+    v = m.scene_view()
+    bvh = m.arrays()["bvh"].copy()
+    grow = np.float32(0.04 * float((bvh["max"][0] - bvh["min"][0]).max()))
+    big = bvh.copy()
+    big["min"] -= grow; big["max"] += grow
+    out = {}
+    for name, tree in (("tight", bvh), ("grown", big)):
+        v.bvh = tree.ctypes.data
+        tracer.scene_upload(v)
+        tracer.set_camera(tr, W, H)
+        tracer.set_decay_origin((0, 0, 0, 1))
+        out[name] = (tracer.render(max_depth=4, mode=abi.MODE_FAST), tracer.scene_info()["ownBoxes"])
+    assert out["tight"][1] == 0 and out["grown"][1] == v.num.triangleNum        # (the tight tree's leaf boxes are the triangles' own)
+    oimg, ohits, _ = O.render(v, tr, W, H, max_depth=4, threads=8)              # the oracle on the grown tree
+    assert (out["grown"][0][1] == ohits).all(axis=-1).mean() >= ID_BAR
+    check_image(out["grown"][0][0], oimg, abi.MODE_FAST, "bunny, grown boxes, fitted")
+    assert (out["grown"][0][1] == out["tight"][0][1]).all(axis=-1).mean() >= ID_BAR
+    moved = (out["grown"][0][0].view(np.uint32) != out["tight"][0][0].view(np.uint32)).any(axis=-1).mean()
+    assert moved <= 1e-4, moved                                                 # (floating-point tie edges only)
+    # not nested: no fit
+    bad = big.copy()
+    leaf = int(np.flatnonzero((bad["leftChild"] == 0) & (bad["geometry"] == 2))[1000])
+    bad["max"][leaf, 2] = bad["max"][0, 2] + 1.0
+    v.bvh = bad.ctypes.data
+    tracer.scene_upload(v)
+    assert tracer.scene_info()["ownBoxes"] == 0
+    tracer.set_camera(tr, W, H)
+    got = tracer.render(max_depth=4, mode=abi.MODE_FAST)
+    assert (got[1] == ohits).all(axis=-1).mean() >= ID_BAR
+
+
 def test_a_moved_scene_is_fitted_again_when_it_pays(pool_model):
     """The Pool's binding syncs the water's triangles on the device once at start-up (lrl_water_init + lrl_water_step(0),
     Pool/Pool.cpp:648-650): they have moved under the caller's tree, so its boxes alone decide.  Once the frames rendered since the move
