@@ -1101,6 +1101,40 @@ def test_parked_primitives_are_bounded_by_their_own_boxes(tracer, pool_model):
     assert np.array_equal(a[1], c[1]) and np.array_equal(a[0].view(np.uint32), c[0].view(np.uint32))
 
 
+def test_refit_after_a_host_side_triangle_update(pool_model):
+    """lrl_scene_update_triangles with moved vertices keeps the triangles' own boxes current on the host, so the fit that follows (here:
+    one frame large enough to pay for it) needs nothing from the device: a parked water triangle lowered inside its node's box is found
+    where the oracle finds it, on the fitted tree."""
+    from raytracing_amd import tracer as T
+    g = load_golden("pool_viewB_192")
+    tris = pool_model.arrays()["triangles"]
+    bvh = pool_model.arrays()["bvh"]
+    parked = np.flatnonzero((bvh["leftChild"] != 0) & (bvh["geometry"] == 2) & (bvh["geometryNum"] < 2 * 47 * 47))
+    pick = parked[np.argmax(bvh["max"][parked, 2] - bvh["min"][parked, 2] > 0.05)]
+    ti = int(bvh["geometryNum"][pick])
+    moved = tris[ti:ti + 1].copy()
+    for f in ("p1", "p2", "p3"):
+        moved[f][:, 2] -= 0.04
+    W = H = 512
+    jit = host.jitter_table(64)                                   # 16.8 M paths: more than 2048 per node of the Pool's tree
+    t = T.Tracer(0)
+    try:
+        t.scene_upload(pool_model.scene_view())
+        t.set_camera(g["trans"], W, H)
+        t.set_decay_origin((0, 0, 0, 1))
+        fitted = t.scene_info()["ownBoxes"]
+        t.update_triangles(ti, moved)
+        assert t.scene_info()["ownBoxes"] == 0
+        img, hits = t.render(max_depth=8, variant=abi.VARIANT_POOL, mode=abi.MODE_FAST, jitter=jit)
+        assert t.scene_info()["ownBoxes"] == fitted                # fitted again, before that frame
+    finally:
+        t.close()
+    all_tris = tris.copy(); all_tris[ti] = moved[0]
+    oimg, ohits, _ = O.render(view_with(pool_model, all_tris), host.sample_trans(g["trans"], jit), W, H, max_depth=8, variant=abi.VARIANT_POOL, threads=16)
+    assert (hits == ohits).all(axis=-1).mean() >= ID_BAR
+    check_image(img, oimg, abi.MODE_FAST, "fitted again after a host-side update")
+
+
 def test_oversized_boxes_of_a_callers_tree_are_fitted(tracer, bunny0_model):
     """Any caller's tree whose boxes are larger than what they hold gains from the fit, not only the Pool's: the bunny's median-split tree
     with every box grown by 4 % of the scene (still nested, still valid for the reference's traversal) renders the oracle's image of
