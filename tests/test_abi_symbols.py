@@ -30,3 +30,33 @@ def test_null_arguments_are_rejected_without_a_gpu():
     assert L.lrl_create(0, None) == 1           # LRL_ERR_INVALID_ARG
     assert L.lrl_destroy(None) == 1
     assert L.lrl_last_error(None) == b"null context"
+
+
+def test_ctypes_mirrors_have_the_headers_layout(tmp_path):
+    """The ctypes structures of raytracing_amd/abi.py against include/lrl_trace.h as a C compiler lays it out: size of every structure that
+    crosses the ABI and the offset of its last field (a field added on one side only moves both)."""
+    import shutil
+    import subprocess
+
+    from raytracing_amd import abi
+    pairs = [("LrlGeometryNum", abi.GeometryNum, "_pad"), ("LrlSceneView", abi.SceneView, "cubeBGR"), ("LrlRenderParams", abi.RenderParams, "rowShard"),
+             ("LrlTuning", abi.Tuning, "debug"), ("LrlSceneInfo", abi.SceneInfo, "ownBoxes"), ("LrlRenderInfo", abi.RenderInfo, "handoverTrips"),
+             ("LrlCounters", abi.Counters, "recordFetches")]
+    src = tmp_path / "layout.c"
+    src.write_text('#include <stdio.h>\n#include <stddef.h>\n#include "lrl_trace.h"\nint main(void) {\n' +
+                   "".join(f'    printf("{c} %zu %zu\\n", sizeof({c}), offsetof({c}, {last}));\n' for c, _, last in pairs) + "    return 0;\n}\n")
+    exe = tmp_path / "layout"
+    cc = shutil.which("gcc")
+    assert cc, "gcc is part of the image"
+    r = subprocess.run([cc, "-std=c11", "-I" + os.path.join(REPO, "include"), str(src), "-o", str(exe)], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    out = dict((l.split()[0], (int(l.split()[1]), int(l.split()[2]))) for l in subprocess.run([str(exe)], capture_output=True, text=True).stdout.splitlines())
+    for c, mirror, last in pairs:
+        assert out[c] == (ctypes.sizeof(mirror), getattr(mirror, last).offset), (c, out[c], ctypes.sizeof(mirror), getattr(mirror, last).offset)
+    # the reference's record layouts (include/lrl_types.h) against the numpy dtypes
+    src.write_text('#include <stdio.h>\n#include "lrl_types.h"\nint main(void) { printf("%zu %zu %zu %zu %zu %zu %zu %zu %zu %zu\\n", sizeof(LrlColor), sizeof(LrlBVHNode), '
+                   'sizeof(LrlTriangle), sizeof(LrlTriangleGPU), sizeof(LrlSphere), sizeof(LrlCircle), sizeof(LrlCylinder), sizeof(LrlCone), sizeof(LrlPointLight), sizeof(LrlTrans)); return 0; }\n')
+    r = subprocess.run([cc, "-std=c11", "-I" + os.path.join(REPO, "include"), str(src), "-o", str(exe)], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    sizes = [int(x) for x in subprocess.run([str(exe)], capture_output=True, text=True).stdout.split()]
+    assert sizes == [d.itemsize for d in (abi.COLOR, abi.BVHNODE, abi.TRIANGLE, abi.TRIANGLE_GPU, abi.SPHERE, abi.CIRCLE, abi.CYLINDER, abi.CONE, abi.POINTLIGHT, abi.TRANS)]
