@@ -43,6 +43,95 @@ def render(view, trans, width, height, max_depth=10, variant=abi.VARIANT_BVH, de
     return img, hits, cn
 
 
+def render_bruteforce(view, trans, width, height, pixels, threads=1):
+    """Tree-free closest hit of the primary rays of `pixels` ([n, 2] of x, y): every primitive against every ray, the oracle's own
+    test arithmetic, no BVH (oracle_bruteforce_primary).  -> (hits [n, 2] uint32 {type, idx}, t [n] float32, -1 = miss)"""
+    trans = np.ascontiguousarray(trans, dtype=abi.TRANS).reshape(-1)
+    px = np.ascontiguousarray(pixels, dtype=np.uint32).reshape(-1, 2)
+    n = px.shape[0]
+    hits = np.zeros((n, 2), dtype=np.uint32)
+    t = np.zeros(n, dtype=np.float32)
+    f = lib().oracle_bruteforce_primary
+    f.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint32, C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p]
+    rc = f(C.byref(view), trans.ctypes.data_as(C.c_void_p), width, height, n, px.ctypes.data_as(C.c_void_p), threads,
+           hits.ctypes.data_as(C.c_void_p), t.ctypes.data_as(C.c_void_p))
+    if rc != 0:
+        raise RuntimeError(f"oracle_bruteforce_primary failed ({rc})")
+    return hits, t
+
+
+def tie_probe(view, trans, width, height, pixels, prims):
+    """For n {pixel, primitive} pairs: (t, signed distance to the primitive's boundary, rounding band), see oracle_tie_probe."""
+    trans = np.ascontiguousarray(trans, dtype=abi.TRANS).reshape(-1)
+    px = np.ascontiguousarray(pixels, dtype=np.uint32).reshape(-1, 2)
+    pr = np.ascontiguousarray(prims, dtype=np.uint32).reshape(-1, 2)
+    n = px.shape[0]
+    t, sd, tol = (np.zeros(n, dtype=np.float32) for _ in range(3))
+    if n == 0:
+        return t, sd, tol
+    f = lib().oracle_tie_probe
+    f.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+    rc = f(C.byref(view), trans.ctypes.data_as(C.c_void_p), width, height, n, px.ctypes.data_as(C.c_void_p), pr.ctypes.data_as(C.c_void_p),
+           t.ctypes.data_as(C.c_void_p), sd.ctypes.data_as(C.c_void_p), tol.ctypes.data_as(C.c_void_p))
+    if rc != 0:
+        raise RuntimeError(f"oracle_tie_probe failed ({rc})")
+    return t, sd, tol
+
+
+def tie_adjusted_match(a, b, view, trans, width, height, pixels=None, row0=0):
+    """Share of pixels whose primary-hit ids {type, idx} agree or are a PROVEN floating-point tie (north_star: "mismatches allowed only
+    at floating-point tie edges").  a, b: [rows, W, 2] id images (rows row0.. of a width x height frame), or [n, 2] lists with
+    `pixels` [n, 2] = their {x, y}.  For every mismatching pixel the primary ray is intersected, in double precision, with both
+    primitives (oracle_tie_probe).  The pixel is a tie when
+      * both are met at the same distance, each within the float32 rounding band of its own patch (two triangles at a shared edge or
+        vertex, coincident discs, a box face lying in the ground disc), or
+      * the NEARER of the two is met within the rounding band of its boundary (a silhouette edge: one arithmetic sees the primitive,
+        the other sees past it; a miss counts as infinitely far).
+    -> (tie-adjusted share, exact share, array of the pixels {x, y} that are neither)"""
+    a, b = np.asarray(a), np.asarray(b)
+    if pixels is None:
+        same = (a == b).all(axis=-1)
+        ys, xs = np.nonzero(~same)
+        pa, pb = a[ys, xs], b[ys, xs]
+        px = np.stack([xs, ys + row0], axis=1).astype(np.uint32)
+    else:
+        same = (a == b).all(axis=-1)
+        bad = np.nonzero(~same)[0]
+        pa, pb = a[bad], b[bad]
+        px = np.asarray(pixels, dtype=np.uint32).reshape(-1, 2)[bad]
+    total = same.size
+    if px.shape[0] == 0:
+        return 1.0, 1.0, px
+    ta, sda, tola = tie_probe(view, trans, width, height, px, pa)
+    tb, sdb, tolb = tie_probe(view, trans, width, height, px, pb)
+    inf = np.float32(np.inf)
+    ta = np.where(ta > 0, ta, inf)
+    tb = np.where(tb > 0, tb, inf)
+    tol = np.maximum(tola, tolb)
+    with np.errstate(invalid="ignore"):
+        equal = (np.abs(ta - tb) <= tol) & (sda <= tola) & (sdb <= tolb)
+        a_near = ta <= tb
+        edge = np.where(a_near, np.abs(sda) <= tola, np.abs(sdb) <= tolb) & np.isfinite(np.minimum(ta, tb))
+    tie = equal | edge
+    return float((same.sum() + tie.sum()) / total), float(same.mean()), px[~tie]
+
+
+def scattered_pixels(width, height, n, seed=1):
+    """n distinct pixels {x, y} spread over the frame: a fixed low-discrepancy set (Halton 2, 3 with a seed offset), no RNG state."""
+    from raytracing_amd import host
+    k = n * 2 + seed
+    xs = (host.halton(k, 2)[seed:] * width).astype(np.uint32)
+    ys = (host.halton(k, 3)[seed:] * height).astype(np.uint32)
+    seen, out = set(), []
+    for x, y in zip(xs, ys):
+        if (int(x), int(y)) not in seen:
+            seen.add((int(x), int(y)))
+            out.append((int(x), int(y)))
+        if len(out) == n:
+            break
+    return np.array(out, dtype=np.uint32)
+
+
 def philox4x32_10(counter):
     ctr = (C.c_uint32 * 4)(*counter)
     out = (C.c_uint32 * 4)()

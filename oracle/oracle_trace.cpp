@@ -343,6 +343,156 @@ bool judgeHit(const Scene& sc, const Ray& ray, Counters& cn) {
 
 struct Hit { uint32_t type = 0, idx = 0; V3 n{0, 0, 0}; float u = 0, v = 0; };
 
+// one primitive against the ray: the body of the shader's switch (RendererFragment0.cpp:419-593); Tp = the triangle's GPU form when geometry == 2
+inline void testPrimitive(const Scene& sc, uint32_t geometry, uint32_t n, const LrlTriangleGPU* Tp, Ray& ray, Hit& hit, Counters& cn) {
+    switch (geometry) {
+        case 2: {
+            ++cn.tri;
+            const LrlTriangleGPU& T = *Tp;
+            float tt = getPlaneT(ray, T.plane);
+            if (tt > 0 && (tt < ray.t || ray.t < 0)) {
+                V3 d = (ray.p0 + ray.n * tt) - v3(T.p1);
+                float u = dot(d, v3(T.k1)), v = dot(d, v3(T.k2));
+                if (u >= 0 && v >= 0 && (u + v <= 1)) {
+                    ray.t = tt;
+                    hit.type = geometry; hit.idx = n;
+                    hit.n = v3(T.plane);
+                    float w = 1 - u - v;
+                    hit.u = w * T.uv1[0] + u * T.uv2[0] + v * T.uv3[0];
+                    hit.v = w * T.uv1[1] + u * T.uv2[1] + v * T.uv3[1];
+                }
+            }
+            break;
+        }
+        case 3: {
+            ++cn.sph;
+            const LrlSphere& S = sc.spheres[n];
+            V3 d = v3(S.sphere) - ray.p0;
+            V3 c = cross(d, ray.n);
+            float s = S.sphere[3] - dot(c, c);
+            if (s >= 0) {
+                s = std::sqrt(s);
+                float k = dot(d, ray.n);
+                float tt = -1;
+                if (k + s > 0) tt = k + s;
+                if (k - s > 0) tt = k - s;
+                if (tt > 0 && (tt < ray.t || ray.t < 0)) {
+                    ray.t = tt;
+                    hit.type = geometry; hit.idx = n;
+                    hit.n = ((ray.p0 + ray.t * ray.n) - v3(S.sphere)) / std::sqrt(S.sphere[3]);
+                    V3 e1 = v3(S.e1), e2 = v3(S.e2);
+                    float ne1 = dot(hit.n, e1);
+                    float ac = std::acos(dot(e2, hit.n) / std::sqrt(1 - ne1 * ne1)) / (2 * kPi);
+                    float u = dot(hit.n, cross(e1, e2)) >= 0 ? ac : 1 - ac;
+                    hit.u = u; hit.v = 1 - std::acos(ne1) / kPi;
+                }
+            }
+            break;
+        }
+        case 4: {
+            ++cn.other;
+            const LrlCircle& C = sc.circles[n];
+            float tt = getPlaneT(ray, C.plane);
+            if (tt > 0 && (tt < ray.t || ray.t < 0)) {
+                V3 d = (ray.p0 + ray.n * tt) - v3(C.sphere);
+                if (dot(d, d) <= C.sphere[3]) {
+                    ray.t = tt;
+                    hit.type = geometry; hit.idx = n;
+                    hit.n = v3(C.plane);
+                    V3 e1 = v3(C.e1);
+                    V3 e2 = cross(hit.n, e1);
+                    float R = std::sqrt(C.sphere[3]);
+                    hit.u = (1 + dot(e1, d) / R) / 2;
+                    hit.v = (1 + dot(e2, d) / R) / 2;
+                }
+            }
+            break;
+        }
+        case 5: {
+            ++cn.other;
+            const LrlCylinder& C = sc.cylinders[n];
+            V3 cnv = v3(C.n);
+            float nn0 = dot(ray.n, cnv);
+            float cnn02 = 1 - nn0 * nn0;
+            if (cnn02 != 0) {
+                V3 d = ray.p0 - v3(C.c);
+                float nd = dot(cnv, d);
+                V3 j = d - nd * cnv;
+                float n0j = dot(ray.n, j);
+                float k = n0j * n0j + cnn02 * (C.r2 - dot(j, j));
+                if (k > 0) {
+                    k = std::sqrt(k);
+                    float tt = -1, v = 0;
+                    if (k - n0j > 0) {
+                        tt = (k - n0j) / cnn02;
+                        v = nd + nn0 * tt;
+                        if (v > C.l || v < 0) tt = -1;
+                    }
+                    if (k + n0j < 0) {
+                        float ttt = -(k + n0j) / cnn02;
+                        float ut = nd + nn0 * ttt;
+                        if (ut <= C.l && ut >= 0) { tt = ttt; v = ut; }
+                    }
+                    if (tt > 0 && (tt < ray.t || ray.t < 0)) {
+                        ray.t = tt;
+                        hit.type = geometry; hit.idx = n;
+                        hit.n = normalize((d + ray.n * ray.t) - cnv * v);
+                        V3 e1 = v3(C.e1);
+                        V3 e2 = cross(cnv, e1);
+                        float ac = std::acos(dot(e1, hit.n)) / (2 * kPi);
+                        hit.u = dot(hit.n, e2) >= 0 ? ac : 1 - ac;
+                        hit.v = v / C.l;
+                    }
+                }
+            }
+            break;
+        }
+        case 6: {
+            ++cn.other;
+            const LrlCone& C = sc.cones[n];
+            V3 cnv = v3(C.n);
+            V3 d = ray.p0 - v3(C.c);
+            float nn0 = dot(ray.n, cnv);
+            float dn = dot(d, cnv);
+            V3 j = dn * cnv - C.c2 * d;
+            float c = dot(d, j);
+            float b = dot(ray.n, j);
+            float a = nn0 * nn0 - C.c2;
+            float s = b * b - a * c;
+            if (s > 0) {
+                s = std::sqrt(s);
+                float r2 = 0;
+                float tt = (s - b) / a;
+                float d2 = dot(d, d);
+                float dn0 = dot(d, ray.n);
+                if (tt > 0) {
+                    r2 = d2 + tt * tt + 2 * dn0 * tt;
+                    float k = dn + nn0 * tt;
+                    if (r2 > C.l2 || k < 0) tt = -1;
+                }
+                float ttt = (-b - s) / a;
+                if (ttt > 0 && (ttt < tt || (tt < 0))) {
+                    float r2t = d2 + ttt * ttt + 2 * dn0 * ttt;
+                    float k = dn + nn0 * ttt;
+                    if (r2t <= C.l2 && k > 0) { tt = ttt; r2 = r2t; }
+                }
+                if (tt > 0 && (tt < ray.t || ray.t < 0)) {
+                    ray.t = tt;
+                    hit.type = geometry; hit.idx = n;
+                    V3 q = d + ray.n * ray.t;
+                    hit.n = (q * std::sqrt(C.c2 / r2) - cnv) / std::sqrt(1 - C.c2);
+                    V3 nxy = normalize(q - cnv * std::sqrt(r2 * C.c2));
+                    V3 e1 = v3(C.e1);
+                    float ac = std::acos(dot(e1, nxy)) / (2 * kPi);
+                    hit.u = dot(nxy, cross(cnv, e1)) >= 0 ? ac : 1 - ac;
+                    hit.v = 1 - std::sqrt(r2 / C.l2);
+                }
+            }
+            break;
+        }
+    }
+}
+
 // ---- closest-hit traversal (:406-632) ----
 void closestHit(const Scene& sc, Ray& ray, Hit& hit, Counters& cn) {
     Trail tr;
@@ -353,152 +503,7 @@ void closestHit(const Scene& sc, Ray& ray, Hit& hit, Counters& cn) {
             uint32_t geometry = bvh[tr.now].geometry;
             if (geometry != 0) {
                 uint32_t n = bvh[tr.now].geometryNum;
-                switch (geometry) {
-                    case 2: {
-                        ++cn.tri;
-                        const LrlTriangleGPU& T = sc.tris[n];
-                        float tt = getPlaneT(ray, T.plane);
-                        if (tt > 0 && (tt < ray.t || ray.t < 0)) {
-                            V3 d = (ray.p0 + ray.n * tt) - v3(T.p1);
-                            float u = dot(d, v3(T.k1)), v = dot(d, v3(T.k2));
-                            if (u >= 0 && v >= 0 && (u + v <= 1)) {
-                                ray.t = tt;
-                                hit.type = geometry; hit.idx = n;
-                                hit.n = v3(T.plane);
-                                float w = 1 - u - v;
-                                hit.u = w * T.uv1[0] + u * T.uv2[0] + v * T.uv3[0];
-                                hit.v = w * T.uv1[1] + u * T.uv2[1] + v * T.uv3[1];
-                            }
-                        }
-                        break;
-                    }
-                    case 3: {
-                        ++cn.sph;
-                        const LrlSphere& S = sc.spheres[n];
-                        V3 d = v3(S.sphere) - ray.p0;
-                        V3 c = cross(d, ray.n);
-                        float s = S.sphere[3] - dot(c, c);
-                        if (s >= 0) {
-                            s = std::sqrt(s);
-                            float k = dot(d, ray.n);
-                            float tt = -1;
-                            if (k + s > 0) tt = k + s;
-                            if (k - s > 0) tt = k - s;
-                            if (tt > 0 && (tt < ray.t || ray.t < 0)) {
-                                ray.t = tt;
-                                hit.type = geometry; hit.idx = n;
-                                hit.n = ((ray.p0 + ray.t * ray.n) - v3(S.sphere)) / std::sqrt(S.sphere[3]);
-                                V3 e1 = v3(S.e1), e2 = v3(S.e2);
-                                float ne1 = dot(hit.n, e1);
-                                float ac = std::acos(dot(e2, hit.n) / std::sqrt(1 - ne1 * ne1)) / (2 * kPi);
-                                float u = dot(hit.n, cross(e1, e2)) >= 0 ? ac : 1 - ac;
-                                hit.u = u; hit.v = 1 - std::acos(ne1) / kPi;
-                            }
-                        }
-                        break;
-                    }
-                    case 4: {
-                        ++cn.other;
-                        const LrlCircle& C = sc.circles[n];
-                        float tt = getPlaneT(ray, C.plane);
-                        if (tt > 0 && (tt < ray.t || ray.t < 0)) {
-                            V3 d = (ray.p0 + ray.n * tt) - v3(C.sphere);
-                            if (dot(d, d) <= C.sphere[3]) {
-                                ray.t = tt;
-                                hit.type = geometry; hit.idx = n;
-                                hit.n = v3(C.plane);
-                                V3 e1 = v3(C.e1);
-                                V3 e2 = cross(hit.n, e1);
-                                float R = std::sqrt(C.sphere[3]);
-                                hit.u = (1 + dot(e1, d) / R) / 2;
-                                hit.v = (1 + dot(e2, d) / R) / 2;
-                            }
-                        }
-                        break;
-                    }
-                    case 5: {
-                        ++cn.other;
-                        const LrlCylinder& C = sc.cylinders[n];
-                        V3 cnv = v3(C.n);
-                        float nn0 = dot(ray.n, cnv);
-                        float cnn02 = 1 - nn0 * nn0;
-                        if (cnn02 != 0) {
-                            V3 d = ray.p0 - v3(C.c);
-                            float nd = dot(cnv, d);
-                            V3 j = d - nd * cnv;
-                            float n0j = dot(ray.n, j);
-                            float k = n0j * n0j + cnn02 * (C.r2 - dot(j, j));
-                            if (k > 0) {
-                                k = std::sqrt(k);
-                                float tt = -1, v = 0;
-                                if (k - n0j > 0) {
-                                    tt = (k - n0j) / cnn02;
-                                    v = nd + nn0 * tt;
-                                    if (v > C.l || v < 0) tt = -1;
-                                }
-                                if (k + n0j < 0) {
-                                    float ttt = -(k + n0j) / cnn02;
-                                    float ut = nd + nn0 * ttt;
-                                    if (ut <= C.l && ut >= 0) { tt = ttt; v = ut; }
-                                }
-                                if (tt > 0 && (tt < ray.t || ray.t < 0)) {
-                                    ray.t = tt;
-                                    hit.type = geometry; hit.idx = n;
-                                    hit.n = normalize((d + ray.n * ray.t) - cnv * v);
-                                    V3 e1 = v3(C.e1);
-                                    V3 e2 = cross(cnv, e1);
-                                    float ac = std::acos(dot(e1, hit.n)) / (2 * kPi);
-                                    hit.u = dot(hit.n, e2) >= 0 ? ac : 1 - ac;
-                                    hit.v = v / C.l;
-                                }
-                            }
-                        }
-                        break;
-                    }
-                    case 6: {
-                        ++cn.other;
-                        const LrlCone& C = sc.cones[n];
-                        V3 cnv = v3(C.n);
-                        V3 d = ray.p0 - v3(C.c);
-                        float nn0 = dot(ray.n, cnv);
-                        float dn = dot(d, cnv);
-                        V3 j = dn * cnv - C.c2 * d;
-                        float c = dot(d, j);
-                        float b = dot(ray.n, j);
-                        float a = nn0 * nn0 - C.c2;
-                        float s = b * b - a * c;
-                        if (s > 0) {
-                            s = std::sqrt(s);
-                            float r2 = 0;
-                            float tt = (s - b) / a;
-                            float d2 = dot(d, d);
-                            float dn0 = dot(d, ray.n);
-                            if (tt > 0) {
-                                r2 = d2 + tt * tt + 2 * dn0 * tt;
-                                float k = dn + nn0 * tt;
-                                if (r2 > C.l2 || k < 0) tt = -1;
-                            }
-                            float ttt = (-b - s) / a;
-                            if (ttt > 0 && (ttt < tt || (tt < 0))) {
-                                float r2t = d2 + ttt * ttt + 2 * dn0 * ttt;
-                                float k = dn + nn0 * ttt;
-                                if (r2t <= C.l2 && k > 0) { tt = ttt; r2 = r2t; }
-                            }
-                            if (tt > 0 && (tt < ray.t || ray.t < 0)) {
-                                ray.t = tt;
-                                hit.type = geometry; hit.idx = n;
-                                V3 q = d + ray.n * ray.t;
-                                hit.n = (q * std::sqrt(C.c2 / r2) - cnv) / std::sqrt(1 - C.c2);
-                                V3 nxy = normalize(q - cnv * std::sqrt(r2 * C.c2));
-                                V3 e1 = v3(C.e1);
-                                float ac = std::acos(dot(e1, nxy)) / (2 * kPi);
-                                hit.u = dot(nxy, cross(cnv, e1)) >= 0 ? ac : 1 - ac;
-                                hit.v = 1 - std::sqrt(r2 / C.l2);
-                            }
-                        }
-                        break;
-                    }
-                }
+                testPrimitive(sc, geometry, n, geometry == 2 ? &sc.tris[n] : nullptr, ray, hit, cn);
             }
             if (bvh[tr.now].bound.leftChild != 0) { tr.descend(bvh, ray); continue; }
         }
@@ -757,6 +762,179 @@ int oracle_render(const LrlSceneView* sv, const LrlTrans* trans, const OraclePar
         counters->raysShadow = total.shadow; counters->nodeVisits = total.nodes; counters->triTests = total.tri;
         counters->sphereTests = total.sph; counters->otherTests = total.other; counters->primaryHits = total.primaryHits;
         counters->recordFetches = 0;
+    }
+    return 0;
+}
+
+// Tree-free closest hit of the PRIMARY rays of `n` pixels {x, y}: every primitive of the scene is tested against every ray, with the
+// same test arithmetic as closestHit above (testPrimitive; triangles through TrianglePre computed on the fly, so a 100 M-triangle
+// scene needs no second copy and no BVH).  It is what checks a scene too large for a host-built tree: the answer does
+// not depend on any tree, node index or byte offset.  Among primitives at exactly the same distance the lowest index wins (the
+// reference takes the first one its traversal meets): callers judge such pixels as floating-point ties.
+// hits: {type, idx} per pixel (0, 0 = miss); tOut: the hit distance (-1 = miss).
+int oracle_bruteforce_primary(const LrlSceneView* sv, const LrlTrans* trans, uint32_t width, uint32_t height, uint32_t n, const uint32_t* pixels,
+                              uint32_t threads, uint32_t* hits, float* tOut) {
+    if (!sv || !trans || !pixels || !hits || !tOut || !n || (sv->num.triangleNum && !sv->trianglesOrigin && !sv->trianglesGPU)) return 1;
+    std::vector<Ray> rays(n);
+    for (uint32_t r = 0; r < n; ++r) rays[r] = primaryRay(trans[0], width, height, pixels[2 * r], pixels[2 * r + 1]);
+    // direction components as arrays: the plane distances of one triangle against all rays are one vectorisable loop
+    std::vector<float> nx(n), ny(n), nz(n);
+    for (uint32_t r = 0; r < n; ++r) { nx[r] = rays[r].n.x; ny[r] = rays[r].n.y; nz[r] = rays[r].n.z; }
+    const V3 p0 = rays[0].p0;      // every primary ray starts at the eye
+    const uint32_t T = sv->num.triangleNum;
+    const int nthreads = threads ? int(threads) : 1;
+    std::vector<float> bestT(size_t(nthreads) * n, -1.0f);
+    std::vector<uint32_t> bestI(size_t(nthreads) * n, 0xffffffffu);
+#ifdef _OPENMP
+#pragma omp parallel num_threads(nthreads)
+#endif
+    {
+#ifdef _OPENMP
+        const int me = omp_get_thread_num();
+#else
+        const int me = 0;
+#endif
+        float* bt = &bestT[size_t(me) * n];
+        uint32_t* bi = &bestI[size_t(me) * n];
+        std::vector<float> tt(n);
+        std::vector<int32_t> okv(n);
+#ifdef _OPENMP
+#pragma omp for schedule(static)
+#endif
+        for (int64_t i = 0; i < int64_t(T); ++i) {      // (static schedule, ascending within a thread: the lowest index wins a tie)
+            LrlTriangleGPU G;
+            const LrlTriangleGPU* g = sv->trianglesGPU ? sv->trianglesGPU + i : &G;
+            if (!sv->trianglesGPU) trianglePre(sv->trianglesOrigin[i], G);
+            const float num = -dot4(g->plane, p0, 1.0f);                       // getPlaneT (:184-187), its numerator the same for every ray
+            const float px = g->plane[0], py = g->plane[1], pz = g->plane[2];
+            const float ax = g->p1[0], ay = g->p1[1], az = g->p1[2];
+            const float k1x = g->k1[0], k1y = g->k1[1], k1z = g->k1[2], k2x = g->k2[0], k2y = g->k2[1], k2z = g->k2[2];
+            float* t = tt.data();
+            int32_t* ok = okv.data();
+            const float *NX = nx.data(), *NY = ny.data(), *NZ = nz.data();
+            // the triangle test of closestHit (:433-448) for all rays at once, element by element in the shader's operation order
+            // (dot(): last component first; no contraction): plane distance, point, affine coordinates, inside test
+#ifdef _OPENMP
+#pragma omp simd
+#endif
+            for (uint32_t r = 0; r < n; ++r) {
+                const float q = num / ((pz * NZ[r] + py * NY[r]) + px * NX[r]);
+                const float dx = (p0.x + NX[r] * q) - ax, dy = (p0.y + NY[r] * q) - ay, dz = (p0.z + NZ[r] * q) - az;
+                const float u = (dz * k1z + dy * k1y) + dx * k1x, v = (dz * k2z + dy * k2y) + dx * k2x;
+                t[r] = q;
+                ok[r] = (q > 0) & (u >= 0) & (v >= 0) & (u + v <= 1);
+            }
+            for (uint32_t r = 0; r < n; ++r)
+                if (ok[r] && (t[r] < bt[r] || bt[r] < 0)) { bt[r] = t[r]; bi[r] = uint32_t(i); }
+        }
+    }
+    Scene sc;      // the few primitives that are no triangles, through the shader's own tests
+    sc.num = sv->num;
+    sc.circles.assign(sv->circles, sv->circles + sv->num.circleNum);
+    for (auto& c : sc.circles) circlePre(c);
+    sc.spheres = sv->spheres; sc.cylinders = sv->cylinders; sc.cones = sv->cones;
+    const uint32_t counts[7] = {0, 0, 0, sv->num.sphereNum, sv->num.circleNum, sv->num.cylinderNum, sv->num.coneNum};
+    Counters cn;
+    for (uint32_t r = 0; r < n; ++r) {
+        float t = -1.0f;
+        uint32_t idx = 0xffffffffu;
+        for (int th = 0; th < nthreads; ++th) {
+            const float q = bestT[size_t(th) * n + r];
+            const uint32_t qi = bestI[size_t(th) * n + r];
+            if (q > 0 && (t < 0 || q < t || (q == t && qi < idx))) { t = q; idx = qi; }
+        }
+        Ray ray = rays[r];
+        ray.t = t;
+        Hit hit;
+        if (t > 0) { hit.type = 2; hit.idx = idx; }
+        for (uint32_t geometry = 3; geometry <= 6; ++geometry)
+            for (uint32_t k = 0; k < counts[geometry]; ++k) testPrimitive(sc, geometry, k, nullptr, ray, hit, cn);
+        hits[2 * r] = hit.type; hits[2 * r + 1] = hit.type ? hit.idx : 0u;
+        tOut[r] = ray.t;
+    }
+    return 0;
+}
+
+// For judging id mismatches as floating-point ties (north_star: "mismatches allowed only at floating-point tie edges"): for each of n
+// {pixel, primitive} pairs, where the pixel's primary ray meets the primitive's carrier surface and how far that point is from the
+// primitive's own patch.  Triangles and discs in double precision from the records: tOut = distance along the ray to the plane (-1:
+// behind the eye or parallel), sdOut = signed in-plane distance of that point to the patch's boundary (negative inside), tolOut = the
+// world-space rounding band of a float32 hit point there: 8 ulp of the largest coordinate involved, over the cosine of incidence (a
+// plane distance at grazing incidence is that much less certain).  Spheres, cylinders, cones: the shader's own float test; sd = -inf on
+// a hit, +inf on a miss.  Type 0 (a miss): t = -1, sd = +inf.
+int oracle_tie_probe(const LrlSceneView* sv, const LrlTrans* trans, uint32_t width, uint32_t height, uint32_t n, const uint32_t* pixels,
+                     const uint32_t* prims, float* tOut, float* sdOut, float* tolOut) {
+    if (!sv || !trans || !pixels || !prims || !tOut || !sdOut || !tolOut) return 1;
+    Scene sc;
+    sc.num = sv->num;
+    sc.circles.assign(sv->circles, sv->circles + sv->num.circleNum);
+    for (auto& c : sc.circles) circlePre(c);
+    sc.spheres = sv->spheres; sc.cylinders = sv->cylinders; sc.cones = sv->cones;
+    const uint32_t counts[7] = {0, 0, sv->num.triangleNum, sv->num.sphereNum, sv->num.circleNum, sv->num.cylinderNum, sv->num.coneNum};
+    const double eps = 8.0 * 1.1920928955078125e-7;
+    Counters cn;
+    for (uint32_t i = 0; i < n; ++i) {
+        const Ray ray = primaryRay(trans[0], width, height, pixels[2 * i], pixels[2 * i + 1]);
+        const uint32_t type = prims[2 * i], idx = prims[2 * i + 1];
+        tOut[i] = -1.0f; sdOut[i] = INFINITY; tolOut[i] = 0.0f;
+        if (type < 2 || type > 6 || idx >= counts[type]) continue;
+        const double o[3] = {ray.p0.x, ray.p0.y, ray.p0.z}, d[3] = {ray.n.x, ray.n.y, ray.n.z};
+        auto band = [&](double t, double cosi) {
+            double scale = t;
+            for (int a = 0; a < 3; ++a) scale = std::max(scale, std::max(std::fabs(o[a]), std::fabs(o[a] + d[a] * t)));
+            return float(eps * scale / std::max(std::fabs(cosi), 1e-3));
+        };
+        if (type == 2) {
+            if (!sv->trianglesOrigin) continue;
+            const LrlTriangle& T = sv->trianglesOrigin[idx];
+            const double p[3][3] = {{T.p1[0], T.p1[1], T.p1[2]}, {T.p2[0], T.p2[1], T.p2[2]}, {T.p3[0], T.p3[1], T.p3[2]}};
+            double e1[3], e2[3], N[3];
+            for (int a = 0; a < 3; ++a) { e1[a] = p[1][a] - p[0][a]; e2[a] = p[2][a] - p[0][a]; }
+            N[0] = e1[1] * e2[2] - e1[2] * e2[1]; N[1] = e1[2] * e2[0] - e1[0] * e2[2]; N[2] = e1[0] * e2[1] - e1[1] * e2[0];
+            const double nl = std::sqrt(N[0] * N[0] + N[1] * N[1] + N[2] * N[2]);
+            if (!(nl > 0)) continue;
+            for (int a = 0; a < 3; ++a) N[a] /= nl;
+            const double den = N[0] * d[0] + N[1] * d[1] + N[2] * d[2];
+            if (den == 0) continue;
+            const double t = (N[0] * (p[0][0] - o[0]) + N[1] * (p[0][1] - o[1]) + N[2] * (p[0][2] - o[2])) / den;
+            if (!(t > 0)) continue;
+            const double P[3] = {o[0] + d[0] * t, o[1] + d[1] * t, o[2] + d[2] * t};
+            // signed distance to the boundary in the plane: inside = on the inner side of all three edges
+            bool inside = true;
+            double nearestOut = INFINITY, nearestIn = INFINITY;
+            for (int k = 0; k < 3; ++k) {
+                const double* A = p[k];
+                const double* B = p[(k + 1) % 3];
+                double ab[3], ap[3];
+                for (int a = 0; a < 3; ++a) { ab[a] = B[a] - A[a]; ap[a] = P[a] - A[a]; }
+                // side: (ab x ap) . N >= 0 inside (counter-clockwise about N)
+                const double cx = ab[1] * ap[2] - ab[2] * ap[1], cy = ab[2] * ap[0] - ab[0] * ap[2], cz = ab[0] * ap[1] - ab[1] * ap[0];
+                const double side = cx * N[0] + cy * N[1] + cz * N[2];
+                const double l2 = ab[0] * ab[0] + ab[1] * ab[1] + ab[2] * ab[2];
+                if (!(l2 > 0)) continue;
+                if (side < 0) inside = false;
+                nearestIn = std::min(nearestIn, std::fabs(side) / std::sqrt(l2));                  // distance to the edge's line
+                const double s = std::min(1.0, std::max(0.0, (ab[0] * ap[0] + ab[1] * ap[1] + ab[2] * ap[2]) / l2));
+                double q2 = 0;
+                for (int a = 0; a < 3; ++a) { const double w = ap[a] - ab[a] * s; q2 += w * w; }
+                nearestOut = std::min(nearestOut, std::sqrt(q2));                                  // distance to the edge segment
+            }
+            tOut[i] = float(t); sdOut[i] = float(inside ? -nearestIn : nearestOut); tolOut[i] = band(t, den);
+        } else if (type == 4) {
+            const LrlCircle& C = sc.circles[idx];
+            const double den = double(C.plane[0]) * d[0] + double(C.plane[1]) * d[1] + double(C.plane[2]) * d[2];
+            if (den == 0) continue;
+            const double t = -(double(C.plane[0]) * o[0] + double(C.plane[1]) * o[1] + double(C.plane[2]) * o[2] + double(C.plane[3])) / den;
+            if (!(t > 0)) continue;
+            double r2 = 0;
+            for (int a = 0; a < 3; ++a) { const double w = o[a] + d[a] * t - double(C.sphere[a]); r2 += w * w; }
+            tOut[i] = float(t); sdOut[i] = float(std::sqrt(r2) - std::sqrt(double(C.sphere[3]))); tolOut[i] = band(t, den);
+        } else {
+            Ray r = ray;
+            Hit h;
+            testPrimitive(sc, type, idx, nullptr, r, h, cn);
+            if (h.type) { tOut[i] = r.t; sdOut[i] = -INFINITY; tolOut[i] = band(double(r.t), 1.0); }
+        }
     }
     return 0;
 }

@@ -43,6 +43,18 @@ FAST_RMSE = 2e-2
 OBSERVED = []               # (what, mode, stats) of every check, dumped at session end (gpurun_out/observed_bars.json)
 
 
+def assert_ids(hits, want, view, trans, width, height, what, row0=0, bar=None):
+    """The id bar (north_star): primary-hit ids identical on >= 99.99 % of the pixels, "with mismatches allowed only at floating-point tie
+    edges": every mismatching pixel is put to the proof (oracle_api.tie_adjusted_match: both primitives met at the same distance
+    within the float32 rounding band, or the nearer one met at its boundary) and only proven ties are forgiven.  The message lists
+    the pixels that are neither equal nor ties.  `trans`: the camera of the sample the ids belong to (sample 0)."""
+    from oracle import oracle_api as O
+    share, exact, bad = O.tie_adjusted_match(hits, want, view, trans, width, height, row0=row0)
+    OBSERVED.append((str(what), -1, {"ids_exact": exact, "ids_tie_adjusted": share, "not_ties": int(len(bad))}))
+    assert share >= (bar or ID_BAR), (what, "ids", {"tie_adjusted": share, "exact": exact, "pixels_that_are_no_ties": bad[:16].tolist(), "count": int(len(bad))})
+    return share, exact
+
+
 def check_image(img, ref, mode, what, frac_bar=None):
     """Assert the image bar of `mode` (0 = PARITY, 1 = FAST) with the observed numbers in the message."""
     st = image_stats(img, ref)

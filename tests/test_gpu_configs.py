@@ -27,26 +27,13 @@ def without_tree(model):
     return v
 
 
-def tie_adjusted_match(a, b, view):
-    """Share of pixels whose primary hits agree or are a floating-point tie: two triangles that share an edge or a vertex (the ray
-    passes within rounding of the shared edge: north_star allows mismatches "only at floating-point tie edges").  Far from a scene of
-    sub-pixel triangles the rounding band of an edge, eps x distance, is a visible fraction of a triangle, so FAST (rcp, fma) and
-    PARITY (IEEE divide) hand a good many edge pixels to different neighbours.  -> (share, exact share, pixels that are neither)"""
-    import ctypes as C
-    same = (a == b).all(axis=-1)
-    n = view.num.triangleNum
-    tri = np.frombuffer((C.c_uint8 * (n * abi.TRIANGLE.itemsize)).from_address(view.trianglesOrigin), dtype=abi.TRIANGLE)
-    ys, xs = np.nonzero(~same)
-    tie = np.zeros(len(ys), dtype=bool)
-    both = (a[ys, xs, 0] == 2) & (b[ys, xs, 0] == 2)
-    ia, ib = a[ys, xs, 1][both], b[ys, xs, 1][both]
-    va = np.stack([tri["p1"][ia], tri["p2"][ia], tri["p3"][ia]], axis=1)      # [k, 3, 3]
-    vb = np.stack([tri["p1"][ib], tri["p2"][ib], tri["p3"][ib]], axis=1)
-    shared = (va[:, :, None, :] == vb[:, None, :, :]).all(axis=-1).any(axis=-1).sum(axis=-1)      # vertices of a found in b
-    tie[both] = shared >= 1
-    ok = same.copy()
-    ok[ys[tie], xs[tie]] = True
-    return float(ok.mean()), float(same.mean()), int((~ok).sum())
+def tie_adjusted_match(a, b, view, trans, W, H, row0=0, pixels=None):
+    """oracle_api.tie_adjusted_match: share of pixels whose primary hits agree or are a proven floating-point tie (both primitives met
+    at the same distance within the float32 rounding band, or the nearer one met at its boundary).  Far from a scene of sub-pixel
+    triangles the rounding band of an edge, eps x distance, is a visible fraction of a triangle, so FAST (rcp, fma) and PARITY (IEEE
+    divide) hand a good many edge pixels to different neighbours.  -> (share, exact share, number of pixels that are neither)"""
+    share, exact, bad = O.tie_adjusted_match(a, b, view, trans, W, H, pixels=pixels, row0=row0)
+    return share, exact, int(len(bad))
 
 
 def test_c5_regime(tracer):
@@ -85,7 +72,8 @@ def test_c5_regime(tracer):
     finally:
         tracer.set_tuning(base)
     view = m.scene_view()
-    same, exact, others = tie_adjusted_match(fhits, phits, view)
+    ts0 = host.sample_trans(tr, jit[:1])               # the ids are sample 0's
+    same, exact, others = tie_adjusted_match(fhits, phits, view, ts0, W, H)
     st = image_stats(fast, par)
     # observed: 99.983 % identical, the rest pairs of triangles sharing an edge (the camera is 5 scene widths away)
     assert same >= ID_BAR and exact >= 0.999, (same, exact, others)
@@ -103,10 +91,53 @@ def test_c5_regime(tracer):
     m.data_init("median")
     ts = host.sample_trans(tr, jit)
     oimg, ohits, oc = O.render(m.scene_view(), ts, W, H, max_depth=4, rows=(r0, r0 + 8), threads=16, diffuse=True)
-    osame, oexact, oothers = tie_adjusted_match(shits, ohits, m.scene_view())
+    osame, oexact, oothers = tie_adjusted_match(shits, ohits, m.scene_view(), ts0, W, H, row0=r0)
     assert osame >= ID_BAR and oexact >= 0.999, (osame, oexact, oothers)
     ost = image_stats(stripe, oimg)
     assert ost["frac_gt_1e-3"] <= 2e-3, ost
+
+
+def test_c5_at_its_own_size(tracer):
+    """C5's scene itself: 9 x 9 copies of the subdivided bunny, 100.5 M triangles, tree built on the device (12.9 GB of node records, 6.4 GB
+    of hot triangle records: byte offsets pass 2^32 three times over, which no smaller scene does), 1920 x 1080, diffuse bounces, depth 4.
+    Checked three ways: (i) a TREE-FREE brute-force oracle (every one of the 100.5 M triangles against the primary rays of 256 scattered
+    pixels, oracle_bruteforce_primary: no tree, no node index, no offset to get wrong) against the PARITY and FAST primary ids at those
+    pixels, with the hit distances; (ii) FAST against PARITY ids over the whole frame, mismatches only at shared edges / vertices;
+    (iii) idempotence and a stripe.  Path: /root/reference/BVH/shaders/RendererFragment0.cpp:406-632."""
+    m = scenes.mesh_scene(subdivisions=2, builder="none", grid=9)
+    W, H = 1920, 1080
+    tr = m.camera(H)
+    view = m.scene_view()
+    assert view.num.triangleNum == 81 * 1240960
+    tracer.scene_upload(without_tree(m))
+    info = tracer.scene_info()
+    assert info["deviceBuilt"] == 1 and info["bvhRecords"] * 64 > (1 << 32), info
+    tracer.set_camera(tr, W, H)
+    tracer.set_decay_origin((0, 0, 0, 1))
+    par, phits = tracer.render(max_depth=4, mode=abi.MODE_PARITY, diffuse=True)
+    fast, fhits = tracer.render(max_depth=4, mode=abi.MODE_FAST, diffuse=True)
+    assert tracer.last_render_info()["compactFrom"] == 2
+    # (i) the brute-force oracle
+    px = O.scattered_pixels(W, H, 256)
+    bhits, bt = O.render_bruteforce(view, tr, W, H, px, threads=16)
+    on_mesh = int((bhits[:, 0] == 2).sum())
+    assert on_mesh >= 32, on_mesh                      # the sample looks at the mesh, not only at the ground and the sky
+    for name, hits in (("PARITY", phits), ("FAST", fhits)):
+        same, exact, others = tie_adjusted_match(hits[px[:, 1], px[:, 0]], bhits, view, tr, W, H, pixels=px)
+        assert others == 0 and exact >= 0.98, (name, same, exact, others)
+    # (ii) FAST against PARITY over the frame
+    same, exact, others = tie_adjusted_match(fhits, phits, view, tr, W, H)
+    assert same >= ID_BAR and exact >= 0.999, (same, exact, others)
+    st = image_stats(fast, par)
+    assert st["frac_gt_1e-3"] <= 5e-3 and np.isfinite(fast).all(), st
+    # (iii) idempotence; a stripe in the middle of the frame
+    again, ahits = tracer.render(max_depth=4, mode=abi.MODE_PARITY, diffuse=True)
+    assert np.array_equal(again, par) and np.array_equal(ahits, phits)
+    fagain, fahits = tracer.render(max_depth=4, mode=abi.MODE_FAST, diffuse=True)
+    assert np.array_equal(fagain.view(np.uint32), fast.view(np.uint32)) and np.array_equal(fahits, fhits)
+    r0 = 536
+    stripe, shits = tracer.render(max_depth=4, mode=abi.MODE_PARITY, diffuse=True, rows=(r0, r0 + 8))
+    assert np.array_equal(stripe, par[r0:r0 + 8]) and np.array_equal(shits, phits[r0:r0 + 8])
 
 
 def test_c4_shape(tracer):

@@ -136,3 +136,82 @@ def test_c1_at_1024_ids_and_tile_sums():
     sums = np.nan_to_num(img[..., :3].astype(np.float64), nan=0.0, posinf=0.0, neginf=0.0).reshape(H // T, T, W // T, T, 3).sum(axis=(1, 3))
     err = np.abs(sums - z["tile_sums"])
     assert err.max() <= 1e-4 + 1e-6 * np.abs(z["tile_sums"]).max(), err.max()
+
+
+# ---- the tree-free brute-force oracle (checks scenes too large for a host tree: C5) against the reference's own ids ----
+@pytest.mark.parametrize("fixture,name", [("default_model", "bvh_viewB_256"), ("default_model", "bvh_viewA_256"), ("bunny0_model", "mesh_bunny0_240x135_depth4"),
+                                          ("pool_model", "pool_viewB_192")])
+def test_bruteforce_oracle_agrees_with_llvmpipe_ids(request, fixture, name):
+    """oracle_bruteforce_primary tests every primitive against the primary rays of 512 scattered pixels, with no tree: its ids equal the
+    ids llvmpipe's run of the reference's shader wrote for those pixels, except where two primitives are hit at exactly the same
+    distance (the reference keeps the first one its traversal meets, the brute force the lowest index; the default scene has coincident
+    discs and box faces), and its distances equal the tree-walking oracle's bit for bit."""
+    model = request.getfixturevalue(fixture)
+    g = load_golden(name)
+    W, H = g["width"], g["height"]
+    px = O.scattered_pixels(W, H, 512)
+    assert len({(int(x), int(y)) for x, y in px}) == 512 and px[:, 0].max() < W and px[:, 1].max() < H
+    hits, t = O.render_bruteforce(model.scene_view(), g["trans"], W, H, px, threads=8)
+    gold = g["ids"][px[:, 1], px[:, 0]]
+    same = (hits == gold).all(axis=-1)
+    # the tree-walking oracle's primary hit distance for the same pixels (golden "t" where the fixture holds it)
+    if "t" in g:
+        gt = g["t"][px[:, 1], px[:, 0]]
+        hit = gold[:, 0] != 0
+        assert np.array_equal(t[hit].view(np.uint32), gt[hit].view(np.uint32)), np.abs(t[hit] - gt[hit]).max()
+        assert same.mean() >= 0.97, same.mean()          # the rest: equal distances (checked by the line above), other primitive of the tie
+    else:
+        assert same.mean() >= ID_BAR, (name, same.mean())
+    assert (hits[:, 0] != 0).sum() >= 64                 # the sample does look at the scene
+
+
+def test_tie_prover_known_answers():
+    """oracle_api.tie_adjusted_match on a scene made for it: two triangles in the plane z = -5 whose shared edge is laid through the point
+    where the primary ray of pixel (40, 20) meets that plane, and whose outer corner is laid through the ray of pixel (12, 50).  {left,
+    right} at the first pixel is a tie; {triangle, miss} at the second (a silhouette) is a tie; the same claims at a pixel deep inside a
+    triangle are not, nor is a triangle claimed where the ray passes far outside it."""
+    W = H = 64
+    m = host.HostModel()
+    m.add_triangles(np.zeros(1, dtype=abi.TRIANGLE))      # (a camera needs a model)
+    m.camera_set(60.0, (0, 0, 0), np.eye(3))
+    tr = m.camera(H)
+    z0 = float(tr["z0"][0])
+
+    def on_plane(x, y):                                   # where the ray of pixel (x, y) meets z = -5
+        d = np.array([2 * (x + 0.5) - W, 2 * (y + 0.5) - H, z0])
+        return d * (-5.0 / d[2])
+    Q, S = on_plane(40, 20), on_plane(12, 50)
+    e = np.array([0.3, 1.0, 0.0])
+    a, b = Q - 1.5 * e, Q + 2.0 * e                       # the shared edge, through Q
+    tri = np.zeros(2, dtype=abi.TRIANGLE)
+    tri["p1"] = [a, a]; tri["p2"] = [b, S]; tri["p3"] = [S, b + (4, 0, 0)]      # triangle 0 = (a, b, S) with its corner at S; triangle 1 on the other side of a-b
+    tri["p2"][1], tri["p3"][1] = b + np.array([4.0, 0, 0]), b
+    for f in ("texR", "texT", "texD", "texG"):
+        tri["color"][f] = -1
+    tri["color"]["n"] = 1.0
+    m2 = host.HostModel()
+    m2.add_triangles(tri)
+    m2.data_init("reference")
+    view = m2.scene_view()
+    t, sd, tol = O.tie_probe(view, tr, W, H, [(40, 20), (40, 20), (12, 50)], [(2, 0), (2, 1), (2, 0)])
+    assert t[0] == t[1] and np.all(t > 5) and np.all(np.abs(sd) <= tol), (t, sd, tol)      # all three rays graze a boundary
+    c0 = (np.asarray(tri["p1"][0]) + tri["p2"][0] + tri["p3"][0]) / 3                       # centroid of triangle 0 -> its pixel
+    cx, cy = int((c0[0] / c0[2] * z0 + W) / 2), int((c0[1] / c0[2] * z0 + H) / 2)
+    ti, sdi, toli = O.tie_probe(view, tr, W, H, [(cx, cy), (cx, cy)], [(2, 0), (2, 1)])
+    assert sdi[0] < -0.1 and sdi[1] > 0.1                                                   # deep inside triangle 0, far outside triangle 1
+    px = [(40, 20), (12, 50), (cx, cy), (cx, cy)]
+    got = np.array([(2, 0), (2, 0), (2, 0), (2, 0)], dtype=np.uint32)
+    want = np.array([(2, 1), (0, 0), (2, 1), (0, 0)], dtype=np.uint32)
+    share, exact, bad = O.tie_adjusted_match(got, want, view, tr, W, H, pixels=px)
+    assert exact == 0.0 and share == 0.5 and bad.tolist() == [[cx, cy], [cx, cy]], (share, exact, bad)
+
+
+def test_tie_prover_on_the_default_scenes_coincident_primitives(default_model):
+    """The default scene holds coincident discs and box faces that lie in the ground disc.  The oracle on a median-split tree meets them in
+    another order than the reference's tree does, so its ids differ from llvmpipe's exactly there: every such pixel is proven a tie
+    (equal distance), and the images agree."""
+    g = load_golden("bvh_viewB_256")
+    m = scenes.bvh_default(builder="median")
+    img, hits, _ = O.render(m.scene_view(), g["trans"], g["width"], g["height"], max_depth=g["depth"], threads=8)
+    share, exact, bad = O.tie_adjusted_match(hits, g["ids"], default_model.scene_view(), g["trans"], g["width"], g["height"])
+    assert share >= ID_BAR and len(bad) == 0, (share, exact, bad[:8])
