@@ -121,21 +121,44 @@ def apply_tuning(tr, spec):
     tr.set_tuning(**kw)
 
 
-def load_traffic(name, match):
-    """PMC passes are separate runs (tools/run_pmc_tag.sh); their per-frame counts live in profiles/.  Returns (HBM bytes of the trace
-    kernels per frame, VALU wave-instructions of the trace kernels per frame or None)."""
-    path = os.path.join(REPO, "profiles", name)
-    if not os.path.exists(path):
-        return None, None
-    tj = json.load(open(path))
-    for k, v in match.items():
-        if tj.get(k) != v:
-            return None, None
-    valu = None
-    src = os.path.join(REPO, tj.get("source", ""))
-    if os.path.isfile(src):
-        valu = json.load(open(src)).get("trace_kernels_per_frame", {}).get("sq", {}).get("SQ_INSTS_VALU")
-    return tj.get("hbm_bytes_per_frame"), valu
+def csrc_hash():
+    """sha256 over the kernel and host sources the library is built from (raytracing_amd/csrc: *.hip, *.inc, *.h, Makefile), in name
+    order.  The PMC summaries under profiles/ carry the hash of the sources they were measured on (tools/summarize_pmc.py); a count
+    from other kernels than the ones being timed must not become this run's roofline numerator."""
+    import hashlib
+    d = os.path.join(REPO, "raytracing_amd", "csrc")
+    h = hashlib.sha256()
+    for n in sorted(os.listdir(d)):
+        if n.endswith((".hip", ".inc", ".h")) or n == "Makefile":
+            h.update(n.encode())
+            h.update(open(os.path.join(d, n), "rb").read())
+    return h.hexdigest()
+
+
+PROFILE_ROUNDS = ("r03", "r02")      # newest first: the PMC record of the round whose kernels these are
+
+
+def load_traffic(suffix, match):
+    """PMC passes are separate runs (tools/run_pmc_tag.sh); their per-frame counts live in profiles/<round>_traffic<suffix>.json.
+    Returns (HBM bytes of the trace kernels per frame, VALU wave-instructions of the trace kernels per frame or None, record): the
+    record says which file, whether the sources it was measured on are the sources of this build (`profile_matches_build`) and with
+    which LrlTuning the pass ran."""
+    for rnd in PROFILE_ROUNDS:
+        name = f"{rnd}_traffic{suffix}.json"
+        path = os.path.join(REPO, "profiles", name)
+        if not os.path.exists(path):
+            continue
+        tj = json.load(open(path))
+        if any(tj.get(k) != v for k, v in match.items()):
+            continue
+        valu = None
+        src = os.path.join(REPO, tj.get("source", ""))
+        if os.path.isfile(src):
+            valu = json.load(open(src)).get("trace_kernels_per_frame", {}).get("sq", {}).get("SQ_INSTS_VALU")
+        rec = {"file": "profiles/" + name, "source": tj.get("source"), "csrc_sha256": tj.get("csrc_sha256"), "tuning": tj.get("tuning"),
+               "profile_matches_build": tj.get("csrc_sha256") == csrc_hash()}
+        return tj.get("hbm_bytes_per_frame"), valu, rec
+    return None, None, None
 
 
 # tools/probes/hbm_gather.hip on this chip (profiles/r02_hbm_gather_probe.txt): what the memory system gives a traversal-shaped stream
@@ -145,6 +168,7 @@ GATHER_PROBE = {"source": "profiles/r02_hbm_gather_probe.txt",
                 "requests_per_s_16GiB_four_lanes_per_record": 45e9,
                 "note": "beyond ~2 GiB a uniformly random gather is bound by address translation per lane, not by HBM; 53 G requests/s x 128 B = 6.8 TB/s"}
 SIMDS, CLOCK_GHZ = 1024, 2.4          # 256 CUs x 4 SIMDs; a wave64 VALU instruction occupies its SIMD for 4 cycles
+FP32_VECTOR_SPEC_TFLOPS = 157.3       # /opt/skills/guides/MI355X_MICROARCH.md: FP32 vector peak (reached only with packed v_pk_fma_f32: 2 x 64 lanes x 2 flop / 4 cycles)
 
 
 class Workload:
@@ -213,9 +237,15 @@ class Workload:
         self.cn = cn
         self.rays, self.alg_bytes = cn.rays, cn.algorithmic_bytes()
         self.fetch_bytes = None
+        self.useful_lane_frac = None
         if self.mode_name == "fast":
             tr.render(count_fetches=True, want_hits=False, **self.kw())
-            self.fetch_bytes = 64 * int(tr.counters().recordFetches)
+            cf = tr.counters()
+            self.fetch_bytes = 64 * int(cf.recordFetches)
+            if cf.waveTrips:
+                # lanes that carried a live ray (lean kernel) or a frontier entry (hand-over kernel), over 64 x the trips of their waves
+                self.useful_lane_frac = float(cf.laneTrips) / (64.0 * float(cf.waveTrips))
+                self.wave_trips = int(cf.waveTrips)
 
     def render_into(self, ptr, stream=None, time_kernels=False):
         self.tr.render_device(ptr, stream=stream, time_kernels=time_kernels, **self.kw())
@@ -247,8 +277,9 @@ class Workload:
         # a FAST frame touches the four-wide nodes (half of `nodes`), the hot triangle records and the cold ones of the hits
         return d["nodes"] // 2 + d["tri_hot"] + d["tri_cold"] + d["other"]
 
-    def roofline(self, kernel_ms, launches, frame_ms, traffic, valu=None):
+    def roofline(self, kernel_ms, launches, frame_ms, traffic, valu=None, profile=None):
         resident = self.working_set() <= INFINITY_CACHE_BYTES
+        stale = profile is not None and not profile["profile_matches_build"]
         r = {"kernel": ("trace kernels of one frame (wfTraceLeanKernel + the hand-over kernel: wfTraceGroupKernel, or wfTraceSwarmKernel beyond the caches)" if self.mode_name == "fast"
                         else "trace kernels of one frame (wfTraceKernel)"),
              "kernel_ms": round(kernel_ms, 4), "launches_per_frame": launches, "frame_ms": round(frame_ms, 4),
@@ -262,8 +293,17 @@ class Workload:
             # VALU issue: PMC pass SQ_INSTS_VALU of the same kernels on the same workload (a count that does not depend on the run: profiles/)
             # over this run's kernel time; a wave64 instruction occupies its 16-lane SIMD for four cycles
             peak = SIMDS * CLOCK_GHZ / 4.0                     # G wave-instructions per second
+            spec = FP32_VECTOR_SPEC_TFLOPS * 1e3 / 128.0       # G wave-instructions/s if every one were a wave64 fma at the guide's FP32 vector peak (128 flop each)
+            busy = valu / (kernel_ms * 1e-3) / 1e9 / peak
             r["valu_issue"] = {"wave_instructions_per_frame": int(valu), "achieved": round(valu / (kernel_ms * 1e-3) / 1e9, 2), "peak": round(peak, 1),
-                               "unit": "G wave-instructions/s", "busy_frac": round(valu / (kernel_ms * 1e-3) / 1e9 / peak, 4),
+                               "unit": "G wave-instructions/s", "busy_frac": round(busy, 4),
+                               "frac_vs_fp32_spec": round(valu / (kernel_ms * 1e-3) / 1e9 / spec, 4), "fp32_spec_peak": round(spec, 1),
+                               "useful_lane_frac": round(self.useful_lane_frac, 4) if self.useful_lane_frac else None,
+                               "useful_busy_frac": round(busy * self.useful_lane_frac, 4) if self.useful_lane_frac else None,
+                               "useful_note": "useful_lane_frac = lanes that carried a live ray (a frontier entry in the hand-over kernel) / (64 x wave-trips), counted by the counting "
+                                              "instantiation of the timed kernels on this run's frame; a wave lives until its longest ray is done, and the idle lanes' instructions are "
+                                              "issued all the same: useful_busy_frac = busy_frac x useful_lane_frac.  frac_vs_fp32_spec prices the same count against the guide's "
+                                              "157.3 TFLOP/s FP32 vector peak (packed fma: two wave64 fmas per 4 cycles), which unpacked code cannot reach",
                                "note": "rocprof's VALUBusy convention: 4 cycles per wave64 instruction (what SQ_ACTIVE_INST_VALU itself counts).  "
                                        "tools/probes/valu_rate.hip (profiles/r02_valu_rate_probe.txt): v_fma / v_max3 / v_cvt_f32_ubyte / v_cmp take 4.0-4.4 cycles, "
                                        "v_mul_f32 / v_mov_b32 2.4-2.6, v_rcp_f32 8.3, so the figure is an upper estimate of the pipe's occupancy (the Pool's "
@@ -299,6 +339,15 @@ class Workload:
             r["hbm_line_requests_per_s"] = round(traffic / 128.0 / (kernel_ms * 1e-3), 0)
             if not resident:
                 r["gather_probe"] = GATHER_PROBE
+        if profile is not None:
+            r["profile"] = profile
+            r["profile_matches_build"] = profile["profile_matches_build"]
+            if stale:
+                # the PMC counts were measured on other sources than the ones this build was made from: they say nothing about these kernels
+                r["stale_frac"] = r.get("frac")
+                r["frac"] = None
+                r["frac_note"] = "profile_matches_build is false: the PMC numerator in profiles/ belongs to other kernels; frac withheld (stale_frac: what it would have been)"
+                return r
         if not (0.0 < r["frac"] <= 1.0):
             r["frac_note"] = ("frac above 1: lanes in step share records, which the per-lane L1 gather peak does not know (l1_note)" if r["bound"] == "l1"
                               else "frac outside (0, 1]: the caches serve part of these bytes; see hbm_frac and work")
@@ -437,6 +486,23 @@ def run(a, torch, dist, sharding, rank, local_rank, world, dev, rehearse):
     for _ in range(warmup):
         step()
     drain()
+    # The library times frames each way before it settles on triangle trips for a scene and frame shape (LrlRenderInfo.trialState = 1
+    # while that is under way): the measured steps start only after the decision, so that they all run the same kernels.  Every rank
+    # takes the same number of extra frames (the collectives pair up): a fixed count after which the state is asserted.
+    extra = 0
+    while wl.tr.last_render_info()["trialState"] == 1 and extra < 24:
+        for _ in range(4):
+            step()
+        drain()
+        extra += 4
+    if world > 1:
+        mx_ex = torch.tensor([extra], dtype=torch.int64, device="cpu" if rehearse else dev)
+        dist.all_reduce(mx_ex, op=dist.ReduceOp.MAX)
+        for _ in range(int(mx_ex[0]) - extra):
+            step()
+        drain()
+        extra = int(mx_ex[0])
+    settled = wl.tr.last_render_info()["trialState"] != 1
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
@@ -456,9 +522,17 @@ def run(a, torch, dist, sharding, rank, local_rank, world, dev, rehearse):
     rinfo = wl.tr.last_render_info()
 
     tot = torch.tensor([elapsed, float(wl.rays)], dtype=torch.float64, device=dev)
+    per_rank_ms = [elapsed / steps * 1e3]
+    backend = None
     if world > 1:
+        backend = dist.get_backend()
+        if rehearse:
+            tot = tot.cpu()
         mx = tot.clone()
         dist.all_reduce(mx, op=dist.ReduceOp.MAX)
+        every = [torch.zeros_like(tot) for _ in range(world)]
+        dist.all_gather(every, tot)
+        per_rank_ms = [float(e[0]) / steps * 1e3 for e in every]
         dist.all_reduce(tot, op=dist.ReduceOp.SUM)
         elapsed, rays_all = float(mx[0]), float(tot[1])
     else:
@@ -470,16 +544,18 @@ def run(a, torch, dist, sharding, rank, local_rank, world, dev, rehearse):
     ms_per_step = elapsed / steps * 1e3
     value = rays_all * steps / elapsed / 1e6
     frame_ms = frame_ms_total / max(frames, 1)
-    traffic = valu = None
+    traffic = valu = profile = None
     # (weak scaling: rank 0's frame is the one-GPU frame with its own sample index, the same kernels over the same scene)
     if (world == 1 or scaling == "weak") and a.workload == "c2" and not a.tuning:
-        traffic, valu = load_traffic("r02_traffic.json", {"workload_triangles": int(wl.view.num.triangleNum), "mode": a.mode, "builder": wl.builder,
-                                                    "width": W, "height": H, "spp": wl.spp, "depth": wl.depth, "diffuse": wl.diffuse})
+        traffic, valu, profile = load_traffic("", {"workload_triangles": int(wl.view.num.triangleNum), "mode": a.mode, "builder": wl.builder,
+                                                   "width": W, "height": H, "spp": wl.spp, "depth": wl.depth, "diffuse": wl.diffuse})
     if world == 1 and a.workload == "c5" and not a.tuning and not (a.grid or a.spp or a.depth or a.width or a.builder or a.diffuse):
-        traffic, valu = load_traffic("r02_traffic_c5.json", {"workload_triangles": int(wl.view.num.triangleNum), "spp": wl.spp, "depth": wl.depth})
+        traffic, valu, profile = load_traffic("_c5", {"workload_triangles": int(wl.view.num.triangleNum), "spp": wl.spp, "depth": wl.depth})
     if world > 1:
-        par = (f"replicated scene, {wl.spp} sample indices per GPU, RCCL reduce of the image onto rank 0" + (" overlapping the next frame" if overlap else "")
-               if scaling == "weak" else "replicated scene, interleaved 16-row stripes per GPU, RCCL all-gather of the frame")
+        # the collective library that actually ran: "nccl" is RCCL on ROCm; the one-GPU rehearsal runs gloo on host copies
+        lib_name = {"nccl": "RCCL", "gloo": "gloo (host copies: one-GPU rehearsal, not the measured configuration)"}.get(backend, str(backend))
+        par = (f"replicated scene, {wl.spp} sample indices per GPU, {lib_name} reduce of the image onto rank 0" + (" overlapping the next frame" if overlap else "")
+               if scaling == "weak" else f"replicated scene, interleaved 16-row stripes per GPU, {lib_name} all-gather of the frame")
     else:
         par = "1 GPU"
     line = {
@@ -490,8 +566,11 @@ def run(a, torch, dist, sharding, rank, local_rank, world, dev, rehearse):
                    "bvh_wide_depth": wl.info["wideDepth"], "arithmetic": a.mode, "parallelism": par,
                    "rays_per_frame": int(rays_all), "host_scene_build_s": round(wl.build_s, 2), "scene_upload_s": round(wl.upload_s, 2),
                    "device_scene_bytes": wl.tr.scene_device_bytes(),
-                   "schedule": {k: rinfo[k] for k in ("passes", "batch", "iterations", "compactFrom", "groupLanes", "frontierEntries", "contSlots", "coopFetch", "streamWords", "phasedTrips", "handoverTrips")}},
-        "roofline": wl.roofline(kernel_ms, launches, frame_ms, traffic, valu),
+                   "collective_backend": backend, "ranks_seen_by_backend": dist.get_world_size() if world > 1 else 1,
+                   "ms_per_step_per_rank": [round(x, 4) for x in per_rank_ms],
+                   "schedule": dict({k: rinfo[k] for k in ("passes", "batch", "iterations", "compactFrom", "groupLanes", "frontierEntries", "contSlots", "coopFetch", "streamWords", "phasedTrips", "handoverTrips", "trialState")},
+                                    settled=bool(settled), extra_warmup_frames=extra, deterministic=int(wl.tr.get_tuning().deterministic))},
+        "roofline": wl.roofline(kernel_ms, launches, frame_ms, traffic, valu, profile),
     }
     if not a.no_cpu_baseline and world == 1:
         line["cpu_baseline"] = cpu_baseline(a, wl)
@@ -513,6 +592,11 @@ def roofline_c5(a, local_rank, torch, dev):
     for _ in range(8):
         wl.render_into(out.data_ptr())
     wl.tr.sync()
+    extra = 0
+    while wl.tr.last_render_info()["trialState"] == 1 and extra < 24:      # the library's own timed trial ends before the timed steps begin
+        wl.render_into(out.data_ptr())
+        wl.tr.sync()
+        extra += 1
     wl.tr.timing_begin()
     t0 = time.perf_counter()
     steps = 4
@@ -522,14 +606,48 @@ def roofline_c5(a, local_rank, torch, dev):
     elapsed = time.perf_counter() - t0
     frame_ms_total, frames = wl.tr.timing_end()
     kernel_ms, launches = wl.trace_kernel_ms(out.data_ptr(), 1)
-    traffic, valu = load_traffic("r02_traffic_c5.json", {"workload_triangles": int(wl.view.num.triangleNum), "spp": wl.spp, "depth": wl.depth})
-    r = wl.roofline(kernel_ms, launches, frame_ms_total / max(frames, 1), traffic, valu)
+    rinfo = wl.tr.last_render_info()
+    traffic, valu, profile = load_traffic("_c5", {"workload_triangles": int(wl.view.num.triangleNum), "spp": wl.spp, "depth": wl.depth})
+    r = wl.roofline(kernel_ms, launches, frame_ms_total / max(frames, 1), traffic, valu, profile)
     r.update({"workload": wl.describe(), "bvh_builder": wl.builder, "bvh_depth": wl.info["bvhDepth"], "bvh_wide_depth": wl.info["wideDepth"],
               "Mrays_per_s": round(wl.rays * steps / elapsed / 1e6, 2), "ms_per_frame": round(elapsed / steps * 1e3, 3), "steps": steps,
               "rays_per_frame": int(wl.rays), "host_scene_build_s": round(wl.build_s, 2), "scene_upload_and_build_s": round(wl.upload_s, 2),
-              "device_scene_bytes": wl.tr.scene_device_bytes()})
+              "device_scene_bytes": wl.tr.scene_device_bytes(),
+              "schedule": dict({k: rinfo[k] for k in ("passes", "batch", "iterations", "compactFrom", "groupLanes", "frontierEntries", "phasedTrips", "handoverTrips", "trialState")},
+                               extra_warmup_frames=extra)})
+    if not a.no_cpu_baseline:
+        r["verified"] = verify_c5(wl)
     wl.tr.close()
     return r
+
+
+def verify_c5(wl):
+    """The image behind roofline_c5, looked at: the 100.5 M-triangle scene is the only one whose byte offsets pass 2^32, and no host tree of
+    it is affordable.  (i) A tree-free brute-force oracle (oracle_bruteforce_primary: every triangle against the primary rays of 256
+    scattered pixels; part of the CPU-checker leg like cpu_baseline, never of a timed region) against the FAST and the PARITY primary
+    ids of sample 0; (ii) FAST against PARITY ids over the whole frame; mismatches must be proven floating-point ties
+    (oracle_api.tie_adjusted_match).  Path: /root/reference/BVH/shaders/RendererFragment0.cpp:406-632."""
+    from oracle import oracle_api as O
+    from raytracing_amd import abi, host
+    t0 = time.time()
+    tr0 = host.sample_trans(wl.trans, wl.jitter[:1]) if wl.jitter is not None else wl.trans
+    kw = dict(wl.kw(), samples=(0, 1))
+    _, fhits = wl.tr.render(**dict(kw, mode=abi.MODE_FAST))
+    _, phits = wl.tr.render(**dict(kw, mode=abi.MODE_PARITY))
+    threads = int(os.environ.get("OMP_NUM_THREADS", "0")) or min(16, os.cpu_count() or 1)
+    px = O.scattered_pixels(wl.W, wl.H, 256)
+    bhits, _ = O.render_bruteforce(wl.view if wl.builder != "device" else wl.model.scene_view(), tr0, wl.W, wl.H, px, threads=threads)
+    view = wl.model.scene_view()
+    out = {"pixels": int(px.shape[0]), "pixels_on_triangles": int((bhits[:, 0] == 2).sum()), "oracle": "tree-free brute force, every triangle against every sampled primary ray"}
+    for name, hits in (("fast", fhits), ("parity", phits)):
+        share, exact, bad = O.tie_adjusted_match(hits[px[:, 1], px[:, 0]], bhits, view, tr0, wl.W, wl.H, pixels=px)
+        out[f"ids_{name}_vs_bruteforce"] = {"tie_adjusted": share, "exact": exact, "not_ties": int(len(bad))}
+    share, exact, bad = O.tie_adjusted_match(fhits, phits, view, tr0, wl.W, wl.H)
+    out["ids_fast_vs_parity_whole_frame"] = {"tie_adjusted": round(share, 6), "exact": round(exact, 6), "not_ties": int(len(bad)), "pixels": int(wl.W * wl.H)}
+    out["ids"] = min(out["ids_fast_vs_bruteforce"]["tie_adjusted"], out["ids_parity_vs_bruteforce"]["tie_adjusted"], share)
+    out["ok"] = bool(out["ids"] >= 0.9999 and out["ids_fast_vs_bruteforce"]["not_ties"] == 0 and out["ids_parity_vs_bruteforce"]["not_ties"] == 0)
+    out["seconds"] = round(time.time() - t0, 1)
+    return out
 
 
 def cpu_baseline(a, wl):

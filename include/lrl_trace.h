@@ -135,6 +135,9 @@ typedef struct LrlCounters {
     uint64_t primaryHits;
     uint64_t recordFetches;      /* LRL_FLAG_COUNT_FETCHES: 64-B records (four-wide nodes, triangle hot      */
                                  /* records) the FAST trace kernels fetched; 0 otherwise                      */
+    uint64_t laneTrips;          /* LRL_FLAG_COUNT_FETCHES: lanes that carried a live ray (or a frontier entry), summed over the     */
+    uint64_t waveTrips;          /* trips (rounds) of the FAST trace kernels' waves, and those trips: laneTrips / (64 x waveTrips)   */
+                                 /* is the share of the issued vector work that was some ray's own                                    */
 } LrlCounters;
 
 /* Scheduling knobs of the FAST-mode pipeline (no counterpart in the reference, whose driver schedules its fragment shader).
@@ -177,6 +180,11 @@ typedef struct LrlTuning {
                                  /*   scene that is rebuilt for every one- or two-sample frame                                                         */
     uint32_t debug;              /* 1: per-frame diagnostics on stderr (adds host waits); 2: a line around every HIP call of the   */
                                  /*   render path instead (no added waits); 3: both                                                */
+    uint32_t deterministic;      /* 1: the library decides nothing from measurements: no timed trial of triangle trips (off unless  */
+                                 /*   phasedTrips = 1), no adaptation of the hand-over thresholds from earlier frames' counters, no   */
+                                 /*   hand-over launches left out, no refit of a moved scene at rest.  Every frame of a scene and     */
+                                 /*   frame shape then issues the same launches, the first like the hundredth (the image is the same  */
+                                 /*   bit for bit either way; what is given up is the few per cent the adaptation finds).  0: adaptive */
 } LrlTuning;
 
 /* ---- life cycle ---- */
@@ -191,10 +199,13 @@ int lrl_set_tuning(LrlContext* ctx, const LrlTuning* tuning);
 int lrl_scene_upload(LrlContext* ctx, const LrlSceneView* scene);
 /* Pool: water triangles rewritten every frame; re-runs TrianglePre on [first, first+count). */
 int lrl_scene_update_triangles(LrlContext* ctx, uint32_t first, uint32_t count, const LrlTriangle* tris);
-/* The same update for callers that cannot allocate (a frame loop under HIP graph capture, a tight serving loop, a harness that
- * forbids hipMalloc).  No counterpart in the reference.  Same arguments, same results; it stages the records in a static
+/* The same update for callers that cannot allocate (a tight serving loop, a harness that forbids hipMalloc, host code that runs
+ * beside a HIP graph capture).  No counterpart in the reference.  Same arguments, same results; it stages the records in a static
  * device array of the library (LRL_NOALLOC_MAX_TRIANGLES x 164 B = 10.25 MiB per GPU, held until the process ends) instead of
- * buffers sized to the call, and calls no hipMalloc / hipFree or any other allocating routine.  Limits, refused with
+ * buffers sized to the call, through a pinned host mirror of the same size that lrl_create made, and on its success path calls no
+ * hipMalloc / hipFree or any other allocating routine, device or host (an error return composes its message, which may allocate
+ * host memory).  It is not itself capturable: it returns when its kernels are done (hipStreamSynchronize), because the caller's
+ * array is borrowed only for the call.  Limits, refused with
  * LRL_ERR_LIMIT: count > LRL_NOALLOC_MAX_TRIANGLES; a triangle whose material is not yet in the scene's table (growing the table
  * allocates).  Every context on one GPU shares that GPU's array: calls that overlap on one GPU (two contexts, two threads)
  * race; calls on one context follow each other (the call returns when its kernels are done). */
@@ -300,6 +311,9 @@ typedef struct LrlRenderInfo {       /* of the last wavefront-pipeline render */
     uint32_t streamWords;    /* words per wave of the lean kernel with lane refill (0: one-word waves)                      */
     uint32_t phasedTrips;    /* 1: the lean kernel ran with triangle trips                                                  */
     uint32_t handoverTrips[8]; /* thresholds of the first eight segments as the last pass used them (0: no hand-over)      */
+    uint32_t trialState;     /* the timed trial of triangle trips for this scene and frame shape: 0 none (pinned by phasedTrips,   */
+                             /* deterministic, or not a FAST render), 1 under way (frames are still being timed each way: a        */
+                             /* benchmark warms up until this changes), 2 decided                                                   */
 } LrlRenderInfo;
 int lrl_last_render_info(const LrlContext* ctx, LrlRenderInfo* out);
 

@@ -84,9 +84,14 @@ DI uint64_t spread21(uint32_t v) {      // 21 bits -> every third bit
 }
 
 __global__ __launch_bounds__(256) void mortonKernel(const float4* __restrict__ pmin, const float4* __restrict__ pmax, uint32_t n,
-                                                    const uint32_t* __restrict__ bounds, uint64_t* __restrict__ keys, uint32_t* __restrict__ idx) {
+                                                    const uint32_t* __restrict__ bounds, uint64_t* __restrict__ keys, uint32_t* __restrict__ idx, uint32_t* info) {
     const uint32_t i = blockIdx.x * 256u + threadIdx.x;
     if (i >= n) return;
+    {   // a box with a NaN or an infinity: the build goes on (it ends whatever the boxes), the host refuses the scene (info[2])
+        const float4 a = pmin[i], b = pmax[i];
+        const float s = (a.x + a.y + a.z) + (b.x + b.y + b.z);
+        if (!(fabsf(s) < INFINITY)) info[2] = 1u;
+    }
     const float lo[3] = {fkeyInv(bounds[0]), fkeyInv(bounds[1]), fkeyInv(bounds[2])};
     const float hi[3] = {fkeyInv(bounds[3]), fkeyInv(bounds[4]), fkeyInv(bounds[5])};
     const float4 a = pmin[i], b = pmax[i];
@@ -472,12 +477,17 @@ __global__ __launch_bounds__(LRL_PLOC_SMALL_THREADS) void plocSmallKernel(const 
     if (tid == 0) parentInner[0] = 0xffffffffu;
     __syncthreads();
     uint32_t cnt = n, nodeBase = 0;
+    // A round merges at least one pair as long as unionArea orders the candidate pairs (the smallest one chose each other).  Should a round
+    // ever merge nothing (boxes that compare with nothing: non-finite coordinates), the next one pairs the clusters off by position
+    // (i with i ^ 1), which always merges: the loop ends after at most log2(n) such rounds instead of spinning in a one-workgroup kernel.
+    bool byPosition = false;
     while (cnt > 1u) {
         const uint32_t chunk = (cnt + T - 1u) / T, lo = min(cnt, tid * chunk), hi = min(cnt, lo + chunk);      // chunk <= 64
         for (uint32_t i = lo; i < hi; ++i) {
             const float4 mn = minA[i], mx = maxA[i];
             float best = INFINITY;
             uint32_t bestJ = (i ^ 1u) < cnt ? (i ^ 1u) : i - 1u;
+            if (byPosition) { nn[i] = (i ^ 1u) < cnt ? (i ^ 1u) : i; continue; }
             for (int d = 1; d <= LRL_PLOC_RADIUS; ++d)
                 for (int sgn = 0; sgn < 2; ++sgn) {
                     const long long j = sgn ? (long long)i - d : (long long)i + d;
@@ -530,6 +540,7 @@ __global__ __launch_bounds__(LRL_PLOC_SMALL_THREADS) void plocSmallKernel(const 
             ++ko;
         }
         __syncthreads();
+        byPosition = merges == 0u;                           // (the same sum in every thread)
         cnt = keeps; nodeBase += merges;
         uint32_t* tr = refA; refA = refB; refB = tr;
         float4* t4 = minA; minA = minB; minB = t4;
@@ -559,7 +570,7 @@ size_t lrl_build_scratch_bytes(uint32_t n) {
 }
 
 // pmin / pmax: n primitive boxes (w of pmin = primitive bits).  recs / node4: n records each (n >= 2).  info (host-visible
-// after the stream is synchronised): {height of the binary tree, height of the four-wide tree}.
+// after the stream is synchronised): {height of the binary tree, height of the four-wide tree, 1 if a primitive box is not finite}.
 hipError_t lrl_build_bvh(const float4* pmin, const float4* pmax, uint32_t n, float4* recs, uint4* node4, void* scratch, size_t scratchBytes,
                          uint32_t* infoDev, bool ploc, hipStream_t stream) {
     if (n < 2) return hipErrorInvalidValue;
@@ -588,10 +599,10 @@ hipError_t lrl_build_bvh(const float4* pmin, const float4* pmax, uint32_t n, flo
     const uint32_t initBounds[6] = {0xffffffffu, 0xffffffffu, 0xffffffffu, 0u, 0u, 0u};
     if ((e = hipMemcpyAsync(bounds, initBounds, sizeof(initBounds), hipMemcpyHostToDevice, stream)) != hipSuccess) return e;
     if ((e = hipMemsetAsync(counters, 0, N * 4, stream)) != hipSuccess) return e;
-    if ((e = hipMemsetAsync(infoDev, 0, 8, stream)) != hipSuccess) return e;
+    if ((e = hipMemsetAsync(infoDev, 0, 16, stream)) != hipSuccess) return e;
     const dim3 blk(256), grd((n + 255) / 256);
     hipLaunchKernelGGL(lrl_build::boundsKernel, dim3(std::min<uint32_t>(grd.x, 4096u)), blk, 0, stream, pmin, pmax, n, bounds);
-    hipLaunchKernelGGL(lrl_build::mortonKernel, grd, blk, 0, stream, pmin, pmax, n, bounds, keysA, idxA);
+    hipLaunchKernelGGL(lrl_build::mortonKernel, grd, blk, 0, stream, pmin, pmax, n, bounds, keysA, idxA, infoDev);
     if ((e = rocprim::radix_sort_pairs(sortBuf, sortTmp, keysA, keysB, idxA, idxB, N, 0, 63, stream)) != hipSuccess) return e;
     if (ploc) {
         uint32_t* refA = reinterpret_cast<uint32_t*>(take(N * 4)); uint32_t* refB = reinterpret_cast<uint32_t*>(take(N * 4));

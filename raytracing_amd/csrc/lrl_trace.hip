@@ -104,7 +104,9 @@ struct LrlContext {
     LrlTuning tuning{};
     LrlRenderInfo renderInfo{};
     void* noallocScratch = nullptr;     // this device's copy of the static staging array (lrl_scene_update_triangles_noalloc)
-    std::vector<uint32_t> noallocMat;   // LRL_NOALLOC_MAX_TRIANGLES material indices, allocated in lrl_create
+    unsigned char* noallocPinned = nullptr;   // pinned host mirror of that array's layout (records, then material indices), allocated in lrl_create: the
+                                        // entry point copies the caller's records here, so that its host-to-device copies are plain DMA from pinned memory
+                                        // (a copy from pageable memory makes the runtime stage, and may make it allocate, behind the caller's back)
     std::vector<float> workPerRay;      // per iteration: frontier entries per handed-over ray, last feedback
     uint32_t feedbackTick = 0;          // samples rendered since the thresholds were reset
     uint32_t contIters = 0;             // words of contHost in flight / ready
@@ -601,9 +603,10 @@ int runDeviceBuild(LrlContext* c, uint32_t prims, uint32_t& recCount, uint32_t& 
     HIP_TRY(c, lrl_build_bvh(static_cast<const float4*>(c->primMin.p), static_cast<const float4*>(c->primMax.p), prims, static_cast<float4*>(c->nodes.p),
                              static_cast<uint4*>(c->nodes32.p), c->buildScratch.p, buildBytes, static_cast<uint32_t*>(c->buildInfo.p),
                              c->tuning.deviceBuilder != 1u, c->stream));
-    uint32_t info[2] = {0, 0};
-    HIP_TRY(c, hipMemcpyAsync(info, c->buildInfo.p, 8, hipMemcpyDeviceToHost, c->stream));
+    uint32_t info[3] = {0, 0, 0};
+    HIP_TRY(c, hipMemcpyAsync(info, c->buildInfo.p, 12, hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(c, hipStreamSynchronize(c->stream));
+    if (info[2]) return fail(c, LRL_ERR_INVALID_ARG, "a primitive has a coordinate that is not finite (NaN or infinity): no tree can bound it");
     if (info[0] == 0 || info[1] == 0) return fail(c, LRL_ERR_DEVICE, "device BVH build did not reach the root");
     if (info[0] + 1 > LRL_MAX_BVH_DEPTH) return fail(c, LRL_ERR_BVH_DEPTH, "device-built BVH deeper than LRL_MAX_BVH_DEPTH");
     depth = info[0];
@@ -637,7 +640,7 @@ LrlTuning defaultTuning() {
     LrlTuning t{};
     t.handoverEarly = LRL_HANDOVER_AUTO; t.handoverLate = LRL_HANDOVER_AUTO; t.handoverListLen = 0;
     t.adapt = 1; t.groupLanes = 0; t.contSlots = 0; t.groupCapX = 0; t.sparseFrom = 5; t.compactFrom = -1; t.coopFetch = 0; t.groupQuad = 0; t.streamWords = 0; t.refillMin = 16; t.phasedTrips = 0; t.deviceBuilder = 0;
-    t.workLow = 12.0f; t.pollLag = 1; t.traceRef = 0; t.batchSlots = 0; t.debug = 0;
+    t.workLow = 12.0f; t.pollLag = 1; t.traceRef = 0; t.batchSlots = 0; t.debug = 0; t.deterministic = 0;
     return t;
 }
 
@@ -692,7 +695,7 @@ int lrl_create(int device, LrlContext** out) {
     for (hipEvent_t& e : c->evIter) ok = ok && hipEventCreateWithFlags(&e, hipEventDisableTiming) == hipSuccess;
     for (hipEvent_t& e : c->phasedTrial.ev) ok = ok && hipEventCreate(&e) == hipSuccess;
     ok = ok && noallocScratchFor(device, &c->noallocScratch) == hipSuccess;
-    if (ok) c->noallocMat.assign(LRL_NOALLOC_MAX_TRIANGLES, 0u);      // host side of the material indices, so that the entry point allocates nothing
+    ok = ok && hipHostMalloc(reinterpret_cast<void**>(&c->noallocPinned), size_t(LRL_NOALLOC_MAX_TRIANGLES) * (sizeof(LrlTriangle) + 4u), hipHostMallocDefault) == hipSuccess;
     if (!ok) {
         (void)lrl_destroy(c);
         return LRL_ERR_DEVICE;
@@ -720,6 +723,7 @@ int lrl_set_tuning(LrlContext* c, const LrlTuning* t) {
     if (t->phasedTrips > 2) return fail(c, LRL_ERR_INVALID_ARG, "phasedTrips must be 0 (by launch size), 1 (on) or 2 (off)");
     if (t->deviceBuilder > 2) return fail(c, LRL_ERR_INVALID_ARG, "deviceBuilder must be 0 (PLOC), 1 (LBVH) or 2 (PLOC)");
     if (t->streamWords > 4096 || t->refillMin > 64) return fail(c, LRL_ERR_INVALID_ARG, "streamWords <= 4096, refillMin <= 64");
+    if (t->deterministic > 1) return fail(c, LRL_ERR_INVALID_ARG, "deterministic must be 0 or 1");
     c->tuning = *t;
     c->phasedTrial.state = 0; c->phasedTrial.signature = 0;
     c->handoverThr.clear();      // the adaptive thresholds start again from the new base values
@@ -732,12 +736,17 @@ int lrl_destroy(LrlContext* c) {
     if (!c) return LRL_ERR_INVALID_ARG;
     (void)hipSetDevice(c->device);
     (void)hipStreamSynchronize(c->stream);
+    // a render issued with lrl_render_async on a stream of the caller's may still be in flight: it reads the buffers freed below and
+    // writes its feedback into the pinned words
+    if (c->renderedOnce && c->evLastRender) (void)hipEventSynchronize(c->evLastRender);
+    if (c->evCont) (void)hipEventSynchronize(c->evCont);
     for (DevBuf* b : {&c->primMin, &c->primMax, &c->buildScratch, &c->buildInfo, &c->waterPoints, &c->waterTris, &c->waterMat, &c->nodes, &c->nodes32, &c->nodes32Loose, &c->triHot, &c->triCold, &c->materials, &c->spheres, &c->circles, &c->cylinders, &c->cones, &c->lights,
                       &c->tex, &c->cube, &c->triStage, &c->matStage, &c->transDev, &c->outDev, &c->hitDev, &c->counterDev, &c->decayDev, &c->timelineDev, &c->wfArena})
         release(*b);
     for (auto& e : c->timingEvents) { (void)hipEventDestroy(e.first); (void)hipEventDestroy(e.second); }
     if (c->aliveHost) (void)hipHostFree(c->aliveHost);
     if (c->contHost) (void)hipHostFree(c->contHost);
+    if (c->noallocPinned) (void)hipHostFree(c->noallocPinned);
     if (c->evCont) (void)hipEventDestroy(c->evCont);
     if (c->evLastRender) (void)hipEventDestroy(c->evLastRender);
     if (c->evSceneReady) (void)hipEventDestroy(c->evSceneReady);
@@ -828,7 +837,7 @@ static int uploadCallerTree(LrlContext* c, const LrlSceneView* s, uint32_t& recC
 // their boxes (the others' are kept current by the update calls), and the fitted copy of the four-wide tree is made anew.  Renders in flight
 // walk the other copy.
 static int refitAtRest(LrlContext* c, uint64_t paths) {
-    if (!c->looseInUse || c->callerTree.empty() || c->deviceBuilt) return LRL_OK;
+    if (!c->looseInUse || c->callerTree.empty() || c->deviceBuilt || c->tuning.deterministic) return LRL_OK;
     c->pathsAtRest += paths;
     if (c->pathsAtRest < 2048ull * c->callerTree.size()) return LRL_OK;
     if (int rc0 = orderAfterRenders(c)) return rc0;      // (a frame in flight on another stream may still walk the copy that is about to be replaced)
@@ -1011,25 +1020,28 @@ int lrl_scene_update_triangles_noalloc(LrlContext* c, uint32_t first, uint32_t c
     if (uint64_t(first) + count > c->num.triangleNum) return fail(c, LRL_ERR_INVALID_ARG, "triangle range out of bounds");
     if (count > LRL_NOALLOC_MAX_TRIANGLES) return fail(c, LRL_ERR_LIMIT, "lrl_scene_update_triangles_noalloc: count exceeds LRL_NOALLOC_MAX_TRIANGLES (the static staging area); update in pieces or use lrl_scene_update_triangles");
     if (!count) return LRL_OK;
-    if (!c->noallocScratch) return fail(c, LRL_ERR_DEVICE, "the static staging area was not resolved for this device");
+    if (!c->noallocScratch || !c->noallocPinned) return fail(c, LRL_ERR_DEVICE, "the static staging area was not resolved for this device");
     HIP_TRY(c, hipSetDevice(c->device));
     if (int rc0 = orderAfterRenders(c)) return rc0;      // (a stream-level wait: allocates nothing)
     // materials: looked up only; a new one would grow the table (host and device allocations)
+    LrlTriangle* const pinTris = reinterpret_cast<LrlTriangle*>(c->noallocPinned);
+    uint32_t* const pinMat = reinterpret_cast<uint32_t*>(c->noallocPinned + size_t(LRL_NOALLOC_MAX_TRIANGLES) * sizeof(LrlTriangle));
     for (uint32_t i = 0; i < count; ++i) {
         ColorKey k;
         std::memcpy(k.w, &tris[i].color, sizeof(k.w));
         auto it = c->materialIndex.find(k);
         if (it == c->materialIndex.end())
             return fail(c, LRL_ERR_LIMIT, "lrl_scene_update_triangles_noalloc: a triangle carries a material that is not in the scene's table (adding one allocates); use lrl_scene_update_triangles");
-        c->noallocMat[i] = it->second;
+        pinMat[i] = it->second;
     }
+    std::memcpy(pinTris, tris, size_t(count) * sizeof(LrlTriangle));
     if (ownTriangleBoxes(c, first, count, tris)) ownBoxesStale(c);      // (written in place: the vector has its size since the scene came)
     unsigned char* const area = static_cast<unsigned char*>(c->noallocScratch);
     LrlTriangle* const stageTris = reinterpret_cast<LrlTriangle*>(area);
     uint32_t* const stageMat = reinterpret_cast<uint32_t*>(area + size_t(LRL_NOALLOC_MAX_TRIANGLES) * sizeof(LrlTriangle));
     // the area keeps the last call's records beyond `count`: nothing reads them, the kernels stop at `count`
-    HIP_TRY(c, hipMemcpyAsync(stageTris, tris, size_t(count) * sizeof(LrlTriangle), hipMemcpyHostToDevice, c->stream));
-    HIP_TRY(c, hipMemcpyAsync(stageMat, c->noallocMat.data(), size_t(count) * 4, hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(c, hipMemcpyAsync(stageTris, pinTris, size_t(count) * sizeof(LrlTriangle), hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(c, hipMemcpyAsync(stageMat, pinMat, size_t(count) * 4, hipMemcpyHostToDevice, c->stream));
     HIP_TRY(c, lrl_launch_triangle_pre(stageTris, stageMat, first, count, static_cast<float4*>(c->triHot.p), static_cast<LrlTriCold*>(c->triCold.p), c->stream));
     if (c->deviceBuilt)      // keep the boxes current for lrl_scene_rebuild_bvh
         HIP_TRY(c, lrl_launch_triangle_boxes(stageTris, first, count, static_cast<float4*>(c->primMin.p), static_cast<float4*>(c->primMax.p), c->stream));
@@ -1282,8 +1294,11 @@ static int renderWavefront(LrlContext* c, const LrlRenderParams* p, const KScene
     LrlContext::PhasedTrial& trial = c->phasedTrial;
     hipEvent_t trialEnd = nullptr;
     bool phased = false;
+    uint32_t trialState = 0;
+    const bool deterministic = tn.deterministic != 0;
     if (special && !coop) {
         if (tn.phasedTrips) phased = tn.phasedTrips == 1;
+        else if (deterministic) phased = false;
         else {
             const uint64_t signature = (Ppix64 * batch) ^ (uint64_t(f.sampleEnd - f.sampleBegin) << 32) ^ (uint64_t(p->maxDepth) << 48) ^ (uint64_t(p->flags & LRL_FLAG_DIFFUSE_BOUNCE) << 52) ^
                                        (uint64_t(pool) << 57) ^ (uint64_t(L) << 58) ^ (ctr ? 1ull << 63 : 0ull);
@@ -1303,6 +1318,7 @@ static int renderWavefront(LrlContext* c, const LrlRenderParams* p, const KScene
                 trialEnd = trial.ev[2 * k + 1];
             } else if (trial.state == 8) phased = trial.choice;
             if (trial.state < 7) ++trial.state;
+            trialState = trial.state == 8 ? 2u : 1u;
         }
     }
     // lane refill (wfTraceLeanStreamKernel): waves that own streamWords words of a launch
@@ -1316,7 +1332,7 @@ static int renderWavefront(LrlContext* c, const LrlRenderParams* p, const KScene
     if (swarmGroup != 64 && (!instantiated || 2 * contStride + 3 * swarmGroup > groupCap)) swarmGroup = 64;
     const bool handoverFits = 2 * contStride + 192 <= LRL_SWARM_CAP;      // else (trees hundreds of levels deep) the lean kernel finishes every ray itself
     const uint32_t sparseFrom = tn.sparseFrom;      // (measured: C2 best with none of its 5, C1 with 8 of its 56, C3 with 4 of its 10)
-    const bool adapt = tn.adapt != 0;
+    const bool adapt = tn.adapt != 0 && !deterministic;
     auto baseThr = [&](uint32_t i) { return tn.handoverListLen ? tn.handoverList[std::min<uint32_t>(i, tn.handoverListLen - 1)] : i < 2 ? handoverEarly : i == 2 ? (handoverEarly + handoverLate) / 2 : handoverLate; };   // few rays left after the first bounces: the waves are free sooner (C2: a plateau around 48,48,32,16,16)
     if (c->handoverThr.empty()) {
         c->handoverThr.resize(LRL_FEEDBACK_ITERS);
@@ -1414,9 +1430,9 @@ static int renderWavefront(LrlContext* c, const LrlRenderParams* p, const KScene
         wf.hitOut = reinterpret_cast<uint2*>(hitDev);
         wf.counters = ctr;
         wf.timeline = nullptr;
-        if (special) feedback();
+        if (special && !deterministic) feedback();
         // the feedback need not be fresh: the first passes after a scene upload, then one pass in eight (and never two in flight)
-        const bool report = special && c->contIters == 0 && (c->feedbackTick++ < 8 || (c->feedbackTick & 7u) == 0);
+        const bool report = special && !deterministic && c->contIters == 0 && (c->feedbackTick++ < 8 || (c->feedbackTick & 7u) == 0);
         wf.feedbackHost = report ? c->contHostDev : nullptr;
         if (report) std::memset(c->contHost, 0, size_t(LRL_FEEDBACK_ITERS) * 32);
         // one fill (a size that is no multiple of 16 B costs a second fill kernel): alive, hand-over counts, work counters
@@ -1509,6 +1525,7 @@ static int renderWavefront(LrlContext* c, const LrlRenderParams* p, const KScene
         ri.compactFrom = compactFrom; ri.coopFetch = coop ? 1u : 0u; ri.streamWords = coop ? 0u : streamWords; ri.phasedTrips = phased ? 1u : 0u; ri.groupLanes = swarmGroup; ri.frontierEntries = swarmGroup == 64 ? LRL_SWARM_CAP : groupCap;
         ri.contSlots = contSlots; ri.contStride = contStride;
         for (uint32_t i = 0; i < 8; ++i) ri.handoverTrips[i] = handoverFits ? c->handoverThr[i] : 0u;
+        ri.trialState = trialState;
     }
     return LRL_OK;
 }
@@ -1716,7 +1733,7 @@ int lrl_render(LrlContext* c, const LrlRenderParams* p, float* rgba, uint32_t* h
         c->counters.raysRefract = v[LRL_CTR_REFRACT]; c->counters.raysShadow = v[LRL_CTR_SHADOW];
         c->counters.nodeVisits = v[LRL_CTR_NODES]; c->counters.triTests = v[LRL_CTR_TRI]; c->counters.sphereTests = v[LRL_CTR_SPH];
         c->counters.otherTests = v[LRL_CTR_OTHER]; c->counters.primaryHits = v[LRL_CTR_PRIMARY_HITS];
-        c->counters.recordFetches = v[LRL_CTR_FETCH];
+        c->counters.recordFetches = v[LRL_CTR_FETCH]; c->counters.laneTrips = v[LRL_CTR_LANE_TRIPS]; c->counters.waveTrips = v[LRL_CTR_WAVE_TRIPS];
     }
     return LRL_OK;
 }

@@ -37,10 +37,20 @@ RMSE_PARITY = 1e-4          # PARITY arithmetic = the reference's operation orde
 # primitive, and one such pixel can differ by 0.5: a plain RMSE bar is decided by a handful of pixels (observed 9 of 25 600 on the Pool's
 # view A: RMSE 5.8e-3).  So FAST is judged by three numbers: the share of pixels that moved by more than 1e-3 (observed <= 8e-4), the RMSE
 # over all other pixels (observed <= 2e-6) and a gross-error guard over all pixels.
-FAST_FRAC = 2e-3
+FAST_FRAC = 2e-3            # ceiling for a check without a pinned record
 FAST_RMSE_TRIM = 2e-5
-FAST_RMSE = 2e-2
-OBSERVED = []               # (what, mode, stats) of every check, dumped at session end (gpurun_out/observed_bars.json)
+FAST_RMSE = 5e-3            # gross-error guard over all pixels ...
+FAST_RMSE_TIE_VIEW = 2e-2   # ... except for the views named below, whose tie pixels are known and explained where they are tested
+FAST_TIE_VIEWS = ("pool_viewA_160",)      # looks along the diagonal of the water grid: 7-9 of 25 600 pixels sit on shared triangle edges (RMSE 5.8e-3)
+# Per-check pins: what each FAST check was observed to give on MI355X (tests/golden/fast_bars.json, written from a run of the suite by
+# tools/pin_fast_bars.py).  A pinned check must stay within 1.5 x its observed share of moved pixels (+ 2 pixels' worth) and 1.5 x its
+# observed trimmed RMSE (+ 1e-7): a change that moves more pixels than the build the pins came from fails, whatever the global ceilings.
+try:
+    import json as _json
+    PINNED = _json.load(open(os.path.join(GOLDEN, "fast_bars.json")))
+except OSError:
+    PINNED = {}
+OBSERVED = []               # (what, mode, stats) of every check, merged at session end into gpurun_out/observed_bars.json
 
 
 def assert_ids(hits, want, view, trans, width, height, what, row0=0, bar=None):
@@ -62,15 +72,30 @@ def check_image(img, ref, mode, what, frac_bar=None):
     if mode == 0:
         assert st["rmse"] <= RMSE_PARITY, (what, "PARITY", st)
     else:
-        assert st["frac_gt_1e-3"] <= (frac_bar or FAST_FRAC) and st["rmse_trim"] <= FAST_RMSE_TRIM and st["rmse"] <= FAST_RMSE, (what, "FAST", st)
+        pixels = img.shape[0] * img.shape[1]
+        pin = PINNED.get(str(what))
+        frac = frac_bar or (min(FAST_FRAC, 1.5 * pin["frac_gt_1e-3"] + 2.0 / pixels) if pin else FAST_FRAC)
+        trim = min(FAST_RMSE_TRIM, 1.5 * pin["rmse_trim"] + 1e-7) if pin else FAST_RMSE_TRIM
+        gross = FAST_RMSE_TIE_VIEW if any(v in str(what) for v in FAST_TIE_VIEWS) else FAST_RMSE
+        assert st["frac_gt_1e-3"] <= frac and st["rmse_trim"] <= trim and st["rmse"] <= gross, (what, "FAST", st, {"bars": (frac, trim, gross), "pinned": pin})
     return st
 
 
 def pytest_sessionfinish(session, exitstatus):
+    """What every check observed, merged into gpurun_out/observed_bars.json (keyed by check and mode: a session that ran part of the
+    suite replaces only its own entries); tools/pin_fast_bars.py copies it to profiles/ and refreshes the pins."""
     if OBSERVED and os.path.isdir(os.path.join(REPO, "gpurun_out")):
         import json
-        with open(os.path.join(REPO, "gpurun_out", "observed_bars.json"), "w") as f:
-            json.dump(OBSERVED, f, indent=0)
+        path = os.path.join(REPO, "gpurun_out", "observed_bars.json")
+        try:
+            old = json.load(open(path))
+            old = old if isinstance(old, dict) else {}
+        except (OSError, ValueError):
+            old = {}
+        for what, mode, st in OBSERVED:
+            old[f"{what}|{mode}"] = st
+        with open(path, "w") as f:
+            json.dump(old, f, indent=0, sort_keys=True)
 
 
 def image_stats(a, b):

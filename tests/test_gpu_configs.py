@@ -290,3 +290,39 @@ def test_two_ranks_drive_the_hip_tracer():
     striped_equal, interleaved_equal, mean_err, alpha_err = q.get()
     assert striped_equal and interleaved_equal          # stripes: bit-identical to the one-rank frame
     assert mean_err <= 2e-6 and alpha_err <= 1e-6       # sample shards: float add order only; partial alphas add up to 1
+
+
+# ---- bench.py's own N > 1 loop (the code the driver's 8-GPU run executes first), rehearsed with two ranks on this one GPU ----
+@pytest.mark.parametrize("scaling", ["weak", "strong"])
+def test_bench_two_rank_loop_rehearsal(scaling):
+    """`python bench.py --gpus 2 --rehearse`: bench.py starts its two ranks itself (torch.distributed.run as a child process), both on
+    GPU 0 with gloo on host copies in place of RCCL (which refuses two ranks on one device), and runs the same step / drain / barrier /
+    max-over-ranks loop as the measured configuration: weak = sample ranges + reduce onto rank 0, strong = interleaved stripes +
+    all-gather + un-interleave.  The JSON line must say what ran: two ranks, the gloo backend, and a whole-job rate that is the two
+    ranks' rays over the slower rank's time.  Frame being sharded: /root/reference/BVH/BVH.cpp:38-43,741-742."""
+    import json
+    import subprocess
+    import sys
+    from conftest import REPO
+    one = subprocess.run([sys.executable, os.path.join(REPO, "bench.py"), "--workload", "c1", "--steps", "2", "--warmup", "1", "--no-cpu-baseline", "--no-c5",
+                          "--scaling", scaling], capture_output=True, text=True, timeout=300, cwd=REPO)
+    assert one.returncode == 0, one.stderr[-2000:]
+    two = subprocess.run([sys.executable, os.path.join(REPO, "bench.py"), "--gpus", "2", "--rehearse", "--workload", "c1", "--steps", "2", "--warmup", "1",
+                          "--no-cpu-baseline", "--scaling", scaling], capture_output=True, text=True, timeout=300, cwd=REPO)
+    assert two.returncode == 0, two.stderr[-2000:]
+    l1 = json.loads([l for l in one.stdout.splitlines() if l.startswith("{")][-1])
+    l2 = json.loads([l for l in two.stdout.splitlines() if l.startswith("{")][-1])
+    assert l1["n_gpus"] == 1 and l2["n_gpus"] == 2 and l2["scaling"] == scaling and l2["steps"] == 2
+    cfg = l2["config"]
+    assert cfg["collective_backend"] == "gloo" and cfg["ranks_seen_by_backend"] == 2 and "gloo" in cfg["parallelism"] and "RCCL" not in cfg["parallelism"]
+    assert len(cfg["ms_per_step_per_rank"]) == 2 and abs(max(cfg["ms_per_step_per_rank"]) - l2["ms_per_step"]) <= 0.05 * l2["ms_per_step"] + 0.5
+    # rays: weak = every rank the whole frame for its own samples (twice the one-rank frame); strong = the frame's rays once, split over the ranks
+    r1, r2 = l1["config"]["rays_per_frame"], cfg["rays_per_frame"]
+    if scaling == "weak":
+        assert 1.9 * r1 <= r2 <= 2.1 * r1, (r1, r2)
+    else:
+        assert 0.95 * r1 <= r2 <= 1.05 * r1, (r1, r2)
+    # value = rays of all ranks over the slower rank's time
+    assert abs(l2["value"] - r2 / (l2["ms_per_step"] * 1e-3) / 1e6) <= 0.01 * l2["value"]
+    # two processes share one GPU and stage their collectives through the host: no speed bar, only sanity against the one-rank rate
+    assert 0.02 * l1["value"] <= l2["value"] <= 2.5 * l1["value"], (l1["value"], l2["value"])

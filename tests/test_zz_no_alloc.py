@@ -51,6 +51,19 @@ def test_noalloc_update_equals_the_allocating_update(pool_model, device_built):
                 ia, ha = a.render(max_depth=8, variant=abi.VARIANT_POOL, mode=mode)
                 ib, hb = b.render(max_depth=8, variant=abi.VARIANT_POOL, mode=mode)
                 assert np.array_equal(ia.view(np.uint32), ib.view(np.uint32)) and np.array_equal(ha, hb), (first, n, mode)
+        # nothing is allocated: free device memory is the same before and after a run of calls of every size (hipMemGetInfo)
+        import torch
+        torch.cuda.synchronize()
+        free0 = torch.cuda.mem_get_info(0)[0]
+        for first, n, dz, seed in ((0, nw, 0.01, 4), (5, 4000, 0.01, 5), (0, 1, 0.01, 6), (0, nw, 0.0, 7)):
+            b.update_triangles_noalloc(first, moved_water(tris[first:], n, dz, seed))
+        torch.cuda.synchronize()
+        assert torch.cuda.mem_get_info(0)[0] == free0
+        a.update_triangles(0, tris[:nw])
+        b.update_triangles_noalloc(0, tris[:nw])
+        if device_built:
+            a.rebuild_bvh()
+            b.rebuild_bvh()
         base, _ = a.render(max_depth=8, variant=abi.VARIANT_POOL)
         b.update_triangles_noalloc(0, tris[:0])          # empty input: nothing happens
         same, _ = b.render(max_depth=8, variant=abi.VARIANT_POOL)
