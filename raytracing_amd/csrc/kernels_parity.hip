@@ -9,9 +9,12 @@ namespace lrl_parity {
 
 // TrianglePre, /root/reference/BVH/shaders/TrianglePreCompute0.cpp:55-80.  One lane per triangle:
 // reads the 160-B origin record (three 16-B + uv loads), writes the 64-B hot and 32-B cold records.
+// The hot record carries the triangle's number in the y of its last quarter: the four-wide kernels read a copy of the hot records in the
+// order of their tree's leaves (triLeaf[posOfTri[i]], lrl_build.hip) and report hits by that number; the copy is written here too when
+// the scene has one (triLeaf != NULL; posOfTri[i] = LRL_REF_NONE: the tree holds no such triangle).
 __global__ __launch_bounds__(256) void trianglePreKernel(const LrlTriangle* __restrict__ in, const uint32_t* __restrict__ material,
                                                          uint32_t first, uint32_t count, float4* __restrict__ triHot,
-                                                         LrlTriCold* __restrict__ triCold) {
+                                                         LrlTriCold* __restrict__ triCold, float4* __restrict__ triLeaf, const uint32_t* __restrict__ posOfTri) {
     uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= count) return;
     const float4* q = reinterpret_cast<const float4*>(in + i);
@@ -25,10 +28,13 @@ __global__ __launch_bounds__(256) void trianglePreKernel(const LrlTriangle* __re
     f3 k1 = (dot3(e2, e2) * e1 - d * e2) / s;
     f3 k2 = (dot3(e1, e1) * e2 - d * e1) / s;
     float4* h = triHot + size_t(first + i) * 4;
-    h[0] = make_float4(n.x, n.y, n.z, -dot3(n, p1));
-    h[1] = make_float4(p1.x, p1.y, p1.z, k1.x);
-    h[2] = make_float4(k1.y, k1.z, k2.x, k2.y);
-    h[3] = make_float4(k2.z, 0.0f, 0.0f, 0.0f);
+    const float4 h0 = make_float4(n.x, n.y, n.z, -dot3(n, p1)), h1 = make_float4(p1.x, p1.y, p1.z, k1.x), h2 = make_float4(k1.y, k1.z, k2.x, k2.y),
+                 h3 = make_float4(k2.z, __uint_as_float(first + i), 0.0f, 0.0f);
+    h[0] = h0; h[1] = h1; h[2] = h2; h[3] = h3;
+    if (triLeaf) {
+        const uint32_t p = posOfTri[first + i];
+        if (p != LRL_REF_NONE) { float4* l = triLeaf + size_t(p) * 4; l[0] = h0; l[1] = h1; l[2] = h2; l[3] = h3; }
+    }
     float4* cold = reinterpret_cast<float4*>(triCold + first + i);
     cold[0] = uvA;                                                      // uv1, uv2
     cold[1] = make_float4(uvB.x, uvB.y, __uint_as_float(material[i]), 0.0f);   // uv3, material

@@ -208,6 +208,7 @@ DI float area(const Item4& t) {
     return dx * dy + dy * dz + dz * dx;
 }
 DI bool inner(uint32_t ref) { return ref != LRL_REF_NONE && !(ref & LRL_REF_LEAF); }
+DI bool triLeaf(uint32_t ref) { return (ref >> LRL_PRIM_TYPE_SHIFT) == ((LRL_REF_LEAF >> LRL_PRIM_TYPE_SHIFT) | 2u); }
 
 // the items of the four-wide node of record r: its children, the larger inner one replaced by ITS children, twice
 DI int expand4(const float4* recs, Item4* it, int n) {
@@ -320,7 +321,7 @@ __global__ __launch_bounds__(256) void height4Kernel(uint32_t n, const uint32_t*
 // fitKernel + height4Kernel; this kernel: a few ms a launch for the first launches, then the cost of reading doneAt).
 __global__ __launch_bounds__(256) void fitLevelKernel(const float4* __restrict__ pmin, const float4* __restrict__ pmax, const uint32_t* __restrict__ idx, uint32_t n,
                                                       const uint2* __restrict__ children, uint32_t* doneAt, uint32_t launch, float4* nodeMin, float4* nodeMax,
-                                                      uint32_t* heights, float4* recs, uint4* node4, uint32_t* h4, uint32_t* info) {
+                                                      uint32_t* heights, float4* recs, uint4* node4, uint32_t* h4, uint32_t* sizeN, uint32_t* sizeT, uint32_t* info) {
     // (a grid-stride loop: late launches find nearly every node done, and dispatching 390 000 workgroups for 100 M nodes costs more than reading their stamps)
     for (uint32_t cur = blockIdx.x * 256u + threadIdx.x; cur + 1u < n; cur += gridDim.x * 256u) {
     if (doneAt[cur] != 0u) continue;
@@ -369,11 +370,15 @@ __global__ __launch_bounds__(256) void fitLevelKernel(const float4* __restrict__
     it[1] = {make_float3(mn[R].x, mn[R].y, mn[R].z), make_float3(mx[R].x, mx[R].y, mx[R].z), ref[R]};
     const int cnt = expand4(recs, it, 2);
     writeNode4(it, cnt, cur + 1u, node4);
-    uint32_t hw = 0;
+    uint32_t hw = 0, sN = 1u, sT = 0u;      // height, four-wide nodes and triangle leaves of the four-wide subtree (for the layout pass below)
     for (int i = 0; i < cnt; ++i)
-        if (inner(it[i].ref)) hw = max(hw, h4[it[i].ref]);
+        if (inner(it[i].ref)) { hw = max(hw, h4[it[i].ref]); sN += sizeN[it[i].ref]; sT += sizeT[it[i].ref]; }
+        else if (triLeaf(it[i].ref)) ++sT;
     h4[cur + 1u] = hw + 1u;
+    sizeN[cur + 1u] = sN; sizeT[cur + 1u] = sT;
     if (cur == 0u) {      // record 0, the virtual parent of the root: the same four items (the root replaced by its children, then as above)
+        sizeN[0] = sN; sizeT[0] = sT;
+        info[3] = sN; info[4] = sT;
         recs[0] = make_float4(bmin.x, bmin.y, bmin.z, __uint_as_float(1u));
         recs[1] = make_float4(bmax.x, bmax.y, bmax.z, __uint_as_float(LRL_REF_NONE));
         recs[2] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
@@ -548,7 +553,105 @@ __global__ __launch_bounds__(LRL_PLOC_SMALL_THREADS) void plocSmallKernel(const 
     }
 }
 
+// ---- the four-wide tree in the order the rays walk it ----
+// The builders address a four-wide node by the record index of the binary node it replaces: about half of those slots are not reachable
+// from the root (their binary nodes were absorbed by an ancestor's node), and a node's children lie wherever the build numbered them.
+// Every L2 miss of the trace kernels pulls a 128-B line for a 64-B record (TCC_EA0_RDREQ_128B = TCC_EA0_RDREQ), so half of the HBM
+// traffic of a scene beyond the caches carried slots nobody asked for; and beyond ~2 GiB a gather is bound by address translations, so
+// records scattered over 6 GB of slots cost more than the same records packed.  This pass writes the reachable nodes, and only
+// those, in a grouped depth-first order: the (up to four) inner children of a node side by side (a ray that enters a node usually
+// looks at several of them: they share lines), then the subtree of each child, one after the other (what a ray touches near its hit
+// lies within a few pages).  The triangles' hot records get the matching order (a node's triangle leaves side by side, subtree by
+// subtree: `triLeaf`, with the primitive's number inside the record), so that a leaf node's triangles share lines too.
+// Positions are a pure function of the subtree sizes (sizeN: four-wide nodes, sizeT: triangle leaves, by record index):
+//   node X at pos(X), children group at gs(X), own triangles from ts(X):  child i -> gs(X) + i;  gs(child i) = gs(X) + k + sum_{j<i} (sizeN(c_j) - 1);
+//   ts(child i) = ts(X) + m + sum_{j<i} sizeT(c_j)                        (k inner children, m triangle leaves of X)
+// so one launch per level of the tree assigns them top-down: a record stamped by the previous launch writes its node at its position,
+// with its refs renamed, and stamps its children.  The visit order of a ray does not depend on where a record lies: same frames, bit for bit.
+__global__ void layoutRootKernel(uint32_t* stamp, uint32_t* pos, uint32_t* gs, uint32_t* ts) {
+    if (threadIdx.x == 0 && blockIdx.x == 0) { stamp[0] = 1u; pos[0] = 0u; gs[0] = 1u; ts[0] = 0u; }
+}
+// assign: triangle leaves get their positions here (posOfTri written); else they are looked up (a second tree over the same triangles)
+__global__ __launch_bounds__(256) void layoutLevelKernel(const uint4* __restrict__ in, uint32_t nRecs, const uint32_t* __restrict__ sizeN, const uint32_t* __restrict__ sizeT,
+                                                         uint32_t* stamp, uint32_t* pos, uint32_t* gs, uint32_t* ts, uint32_t level, uint4* __restrict__ out,
+                                                         uint32_t* posOfTri, uint32_t triCount, int assign) {
+    for (uint32_t r = blockIdx.x * 256u + threadIdx.x; r < nRecs; r += gridDim.x * 256u) {
+        if (stamp[r] != level) continue;
+        const uint4 q0 = in[size_t(r) * 4], q1 = in[size_t(r) * 4 + 1];
+        uint4 q2 = in[size_t(r) * 4 + 2], q3 = in[size_t(r) * 4 + 3];
+        uint32_t refs[4] = {q2.z, q2.w, q3.x, q3.y};
+        uint32_t k = 0, m = 0;
+        for (int i = 0; i < 4; ++i) { k += inner(refs[i]) ? 1u : 0u; m += triLeaf(refs[i]) ? 1u : 0u; }
+        const uint32_t g = gs[r], t = ts[r];
+        uint32_t run = g + k, trun = t + m, ki = 0, mi = 0;
+        for (int i = 0; i < 4; ++i) {
+            const uint32_t ref = refs[i];
+            if (inner(ref)) {
+                if (ref >= nRecs) { refs[i] = LRL_REF_EMPTY4; continue; }      // (cannot happen for a tree the builders made)
+                const uint32_t at = g + ki++;
+                pos[ref] = at; gs[ref] = run; ts[ref] = trun;
+                run += sizeN[ref] - 1u; trun += sizeT[ref];
+                stamp[ref] = level + 1u;
+                refs[i] = at;
+            } else if (triLeaf(ref)) {
+                const uint32_t prim = ref & LRL_PRIM_INDEX_MASK;
+                uint32_t p = LRL_REF_NONE;
+                if (prim < triCount) {
+                    if (assign) { p = t + mi++; posOfTri[prim] = p; }
+                    else p = posOfTri[prim];
+                }
+                refs[i] = p < triCount ? (LRL_REF_LEAF | (2u << LRL_PRIM_TYPE_SHIFT) | p) : LRL_REF_EMPTY4;      // (a triangle the first tree did not hold: no ray finds it)
+            }
+        }
+        q2.z = refs[0]; q2.w = refs[1]; q3.x = refs[2]; q3.y = refs[3];
+        uint4* o = out + size_t(pos[r]) * 4;
+        o[0] = q0; o[1] = q1; o[2] = q2; o[3] = q3;
+    }
+}
+// triLeaf[posOfTri[i]] = triHot[i], with the triangle's number in the record (the kernels report hits by it)
+__global__ __launch_bounds__(256) void triLeafGatherKernel(const float4* __restrict__ triHot, const uint32_t* __restrict__ posOfTri, uint32_t first, uint32_t count,
+                                                           float4* __restrict__ triLeaf) {
+    const uint32_t i = blockIdx.x * 256u + threadIdx.x;
+    if (i >= count) return;
+    const uint32_t p = posOfTri[first + i];
+    if (p == LRL_REF_NONE) return;
+    const float4* s = triHot + size_t(first + i) * 4;
+    float4* d = triLeaf + size_t(p) * 4;
+    float4 h3 = s[3];
+    h3.y = __uint_as_float(first + i);
+    d[0] = s[0]; d[1] = s[1]; d[2] = s[2]; d[3] = h3;
+}
+
 }  // namespace lrl_build
+
+size_t lrl_layout_scratch_bytes(uint32_t nRecs) { return (size_t(nRecs) * 4 + 255) / 256 * 256 * 4; }
+
+// in: nRecs four-wide nodes by record index (root = record 0); sizeN / sizeT: subtree sizes by record index (device); levels: height of the
+// four-wide tree (or more); out: sizeN[0] nodes; posOfTri: triCount entries (assign: written, LRL_REF_NONE where the tree holds no such
+// triangle; else read).  scratch: lrl_layout_scratch_bytes(nRecs).
+hipError_t lrl_layout_node4(const uint4* in, uint32_t nRecs, const uint32_t* sizeN, const uint32_t* sizeT, uint32_t levels, void* scratch, uint4* out,
+                            uint32_t* posOfTri, uint32_t triCount, bool assign, hipStream_t stream) {
+    const size_t part = (size_t(nRecs) * 4 + 255) / 256 * 256;
+    char* p = static_cast<char*>(scratch);
+    uint32_t* stamp = reinterpret_cast<uint32_t*>(p);
+    uint32_t* pos = reinterpret_cast<uint32_t*>(p + part);
+    uint32_t* gs = reinterpret_cast<uint32_t*>(p + 2 * part);
+    uint32_t* ts = reinterpret_cast<uint32_t*>(p + 3 * part);
+    hipError_t e;
+    if ((e = hipMemsetAsync(stamp, 0, size_t(nRecs) * 4, stream)) != hipSuccess) return e;
+    if (assign && triCount && (e = hipMemsetAsync(posOfTri, 0xff, size_t(triCount) * 4, stream)) != hipSuccess) return e;
+    hipLaunchKernelGGL(lrl_build::layoutRootKernel, dim3(1), dim3(64), 0, stream, stamp, pos, gs, ts);
+    const dim3 grid(std::min<uint32_t>((nRecs + 255u) / 256u, 16384u));
+    for (uint32_t level = 1; level <= levels; ++level)
+        hipLaunchKernelGGL(lrl_build::layoutLevelKernel, grid, dim3(256), 0, stream, in, nRecs, sizeN, sizeT, stamp, pos, gs, ts, level, out, posOfTri, triCount, assign ? 1 : 0);
+    return hipGetLastError();
+}
+
+hipError_t lrl_launch_tri_leaf_gather(const float4* triHot, const uint32_t* posOfTri, uint32_t first, uint32_t count, float4* triLeaf, hipStream_t stream) {
+    if (!count) return hipSuccess;
+    hipLaunchKernelGGL(lrl_build::triLeafGatherKernel, dim3((count + 255u) / 256u), dim3(256), 0, stream, triHot, posOfTri, first, count, triLeaf);
+    return hipGetLastError();
+}
 
 hipError_t lrl_launch_triangle_boxes(const LrlTriangle* in, uint32_t first, uint32_t count, float4* pmin, float4* pmax, hipStream_t stream) {
     if (!count) return hipSuccess;
@@ -566,13 +669,17 @@ size_t lrl_build_scratch_bytes(uint32_t n) {
     size_t scanTmp = 0;
     (void)rocprim::exclusive_scan(nullptr, scanTmp, v, v, 0u, size_t(n), rocprim::plus<uint32_t>(), hipStream_t(nullptr));
     // + PLOC: refs x2, boxes x2 x2, nearest, merge, keep, two offsets
-    return sortTmp + scanTmp + N * (16 + 8 + 8 + 8 + 4 + 32 + 4 + 4) + N * (8 + 64 + 20) + 4096 + 32 * 256;
+    return sortTmp + scanTmp + N * (16 + 8 + 8 + 8 + 4 + 32 + 4 + 4 + 8) + N * (8 + 64 + 20) + 4096 + 34 * 256;
 }
+
 
 // pmin / pmax: n primitive boxes (w of pmin = primitive bits).  recs / node4: n records each (n >= 2).  info (host-visible
 // after the stream is synchronised): {height of the binary tree, height of the four-wide tree, 1 if a primitive box is not finite}.
+// sizes[0..1] (may be NULL): where the build left the four-wide subtree sizes (nodes, triangle leaves; by record index) in `scratch`, for
+// lrl_layout_node4; NULL pointers when this build did not make them (fewer than LRL_BUILD_LEVELS_FROM primitives).
 hipError_t lrl_build_bvh(const float4* pmin, const float4* pmax, uint32_t n, float4* recs, uint4* node4, void* scratch, size_t scratchBytes,
-                         uint32_t* infoDev, bool ploc, hipStream_t stream) {
+                         uint32_t* infoDev, bool ploc, const uint32_t** sizes, hipStream_t stream) {
+    if (sizes) sizes[0] = sizes[1] = nullptr;
     if (n < 2) return hipErrorInvalidValue;
     char* p = static_cast<char*>(scratch);
     auto take = [&](size_t bytes) { char* o = p; p += (bytes + 255) / 256 * 256; return o; };
@@ -589,6 +696,8 @@ hipError_t lrl_build_bvh(const float4* pmin, const float4* pmax, uint32_t n, flo
     float4* nodeMax = reinterpret_cast<float4*>(take(N * 16));
     uint32_t* heights = reinterpret_cast<uint32_t*>(take(N * 4));
     uint32_t* h4 = reinterpret_cast<uint32_t*>(take(N * 4));
+    uint32_t* sizeN = reinterpret_cast<uint32_t*>(take(N * 4));      // four-wide subtree sizes by record index (builds by levels), for lrl_layout_node4
+    uint32_t* sizeT = reinterpret_cast<uint32_t*>(take(N * 4));
     uint32_t* bounds = reinterpret_cast<uint32_t*>(take(256));
     size_t sortTmp = 0;
     hipError_t e = rocprim::radix_sort_pairs(nullptr, sortTmp, keysA, keysB, idxA, idxB, N, 0, 63, stream);
@@ -599,7 +708,7 @@ hipError_t lrl_build_bvh(const float4* pmin, const float4* pmax, uint32_t n, flo
     const uint32_t initBounds[6] = {0xffffffffu, 0xffffffffu, 0xffffffffu, 0u, 0u, 0u};
     if ((e = hipMemcpyAsync(bounds, initBounds, sizeof(initBounds), hipMemcpyHostToDevice, stream)) != hipSuccess) return e;
     if ((e = hipMemsetAsync(counters, 0, N * 4, stream)) != hipSuccess) return e;
-    if ((e = hipMemsetAsync(infoDev, 0, 16, stream)) != hipSuccess) return e;
+    if ((e = hipMemsetAsync(infoDev, 0, 32, stream)) != hipSuccess) return e;
     const dim3 blk(256), grd((n + 255) / 256);
     hipLaunchKernelGGL(lrl_build::boundsKernel, dim3(std::min<uint32_t>(grd.x, 4096u)), blk, 0, stream, pmin, pmax, n, bounds);
     hipLaunchKernelGGL(lrl_build::mortonKernel, grd, blk, 0, stream, pmin, pmax, n, bounds, keysA, idxA, infoDev);
@@ -648,12 +757,13 @@ hipError_t lrl_build_bvh(const float4* pmin, const float4* pmax, uint32_t n, flo
         hipLaunchKernelGGL(lrl_build::height4Kernel, grd, blk, 0, stream, n, parentInner, parentLeaf, counters, node4, h4, infoDev);
         return hipGetLastError();
     }
+    if (sizes) { sizes[0] = sizeN; sizes[1] = sizeT; }
     // by levels: `counters` (zeroed above) serves as doneAt.  The tree's height is not known beforehand: after a first run of launches the
     // host looks at info[0] (the root's height, written by the launch that fits the root) every few launches
     uint32_t rootHeight = 0;
     for (uint32_t launch = 1; launch <= LRL_MAX_BVH_DEPTH + 1u; ++launch) {
         hipLaunchKernelGGL(lrl_build::fitLevelKernel, dim3(std::min<uint32_t>(grd.x, 32768u)), blk, 0, stream, pmin, pmax, idxB, n, children, counters, launch, nodeMin, nodeMax, heights, recs,
-                           node4, h4, infoDev);
+                           node4, h4, sizeN, sizeT, infoDev);
         if (launch >= 16u && (launch & 7u) == 0u) {
             if ((e = hipMemcpyAsync(&rootHeight, infoDev, 4, hipMemcpyDeviceToHost, stream)) != hipSuccess) return e;
             if ((e = hipStreamSynchronize(stream)) != hipSuccess) return e;

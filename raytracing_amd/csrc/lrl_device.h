@@ -217,7 +217,13 @@ hipError_t lrl_launch_circle_pre(LrlCircle* circles, uint32_t count, hipStream_t
 hipError_t lrl_launch_triangle_boxes(const LrlTriangle* in, uint32_t first, uint32_t count, float4* pmin, float4* pmax, hipStream_t stream);
 size_t lrl_build_scratch_bytes(uint32_t n);
 hipError_t lrl_build_bvh(const float4* pmin, const float4* pmax, uint32_t n, float4* recs, uint4* node4, void* scratch, size_t scratchBytes,
-                         uint32_t* infoDev, bool ploc, hipStream_t stream);
+                         uint32_t* infoDev, bool ploc, const uint32_t** sizes, hipStream_t stream);
+// The four-wide tree in the order the rays walk it (lrl_build.hip): reachable nodes only, a node's children side by side, subtree after
+// subtree, and the matching order of the triangles' hot records (triLeaf[posOfTri[i]] = triHot[i] with i inside the record).
+size_t lrl_layout_scratch_bytes(uint32_t nRecs);
+hipError_t lrl_layout_node4(const uint4* in, uint32_t nRecs, const uint32_t* sizeN, const uint32_t* sizeT, uint32_t levels, void* scratch, uint4* out,
+                            uint32_t* posOfTri, uint32_t triCount, bool assign, hipStream_t stream);
+hipError_t lrl_launch_tri_leaf_gather(const float4* triHot, const uint32_t* posOfTri, uint32_t first, uint32_t count, float4* triLeaf, hipStream_t stream);
 hipError_t lrl_launch_quantize(const float4* in, uchar4* out, unsigned long long pixels, hipStream_t stream);   // RGBA32F -> RGBA8 (unorm)
 // Pool water simulation: `substeps` x (acceleration, position) on gx * gy points {z, v, a, blank} (<= 16384), then the
 // heights into the corners of the 2 (gx-1) (gy-1) water triangles `tris` (origin records on the device; NULL: no sync)
