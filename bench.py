@@ -274,8 +274,8 @@ class Workload:
 
     def working_set(self):
         d = self.tr.scene_device_bytes()
-        # a FAST frame touches the four-wide nodes (half of `nodes`), the hot triangle records and the cold ones of the hits
-        return d["nodes"] // 2 + d["tri_hot"] + d["tri_cold"] + d["other"]
+        # a FAST frame touches the four-wide nodes in use, one copy of the hot triangle records and the cold ones of the hits
+        return self.info["wideNodes"] * 64 + self.view.num.triangleNum * 64 + d["tri_cold"] + d["other"]
 
     def roofline(self, kernel_ms, launches, frame_ms, traffic, valu=None, profile=None):
         resident = self.working_set() <= INFINITY_CACHE_BYTES

@@ -180,6 +180,11 @@ typedef struct LrlTuning {
                                  /*   scene that is rebuilt for every one- or two-sample frame                                                         */
     uint32_t debug;              /* 1: per-frame diagnostics on stderr (adds host waits); 2: a line around every HIP call of the   */
                                  /*   render path instead (no added waits); 3: both                                                */
+    uint32_t treeLayout;         /* the four-wide tree of the FAST kernels: 0 = laid out in the order the rays walk it at upload / build (reachable   */
+                                 /*   nodes only, a node's children side by side, subtree after subtree; the triangles' hot records in the order of   */
+                                 /*   the leaves: fewer and fuller cache lines, fewer pages; every caller's tree, library-built trees from 65 536      */
+                                 /*   primitives on); 1 = left as built, addressed by binary record index (for A/B measurements: same frames bit for  */
+                                 /*   bit).  Read by lrl_scene_upload, lrl_scene_update_bvh and lrl_scene_rebuild_bvh                                  */
     uint32_t deterministic;      /* 1: the library decides nothing from measurements: no timed trial of triangle trips (off unless  */
                                  /*   phasedTrips = 1), no adaptation of the hand-over thresholds from earlier frames' counters, no   */
                                  /*   hand-over launches left out, no refit of a moved scene at rest.  Every frame of a scene and     */
@@ -297,6 +302,9 @@ typedef struct LrlSceneInfo {
                                 caller's boxes alone decide, as the reference's do while the Pool's water moves under its fixed
                                 tree (Pool/Pool.cpp:250-263), until the next lrl_scene_update_bvh or until the rendering since the
                                 move is worth a new fit (2048 paths per node: the library then fits the tree again by itself).   */
+    uint32_t wideNodes;      /* four-wide nodes in use: the FAST kernels' tree is stored compactly, in the order the rays walk it (a   */
+                             /* node's children side by side, subtree after subtree)                                                  */
+    uint32_t leafOrder;      /* 1: the FAST kernels read a copy of the triangles' hot records in the order of that tree's leaves      */
 } LrlSceneInfo;
 int lrl_scene_info(const LrlContext* ctx, LrlSceneInfo* out);
 typedef struct LrlRenderInfo {       /* of the last wavefront-pipeline render */

@@ -181,9 +181,10 @@ hipError_t lrl_launch_decay_origin(const KScene& sc, const LrlTrans* trans, uint
 }
 
 hipError_t lrl_launch_triangle_pre(const LrlTriangle* in, const uint32_t* material, uint32_t first, uint32_t count, float4* triHot,
-                                   LrlTriCold* triCold, hipStream_t stream) {
+                                   LrlTriCold* triCold, float4* triLeaf, const uint32_t* posOfTri, hipStream_t stream) {
     if (!count) return hipSuccess;
-    hipLaunchKernelGGL(lrl_parity::trianglePreKernel, dim3((count + 255) / 256), dim3(256), 0, stream, in, material, first, count, triHot, triCold);
+    hipLaunchKernelGGL(lrl_parity::trianglePreKernel, dim3((count + 255) / 256), dim3(256), 0, stream, in, material, first, count, triHot, triCold,
+                       posOfTri ? triLeaf : nullptr, posOfTri);
     return hipGetLastError();
 }
 

@@ -29,7 +29,7 @@
 
 // primitives from which steps 4-6 run level by level (fitLevelKernel) instead of as a climb with atomics.  Measured, ms per rebuild,
 // climb / levels: 4446 primitives 0.23 / 0.45, 77 560: 1.22 / 0.98, 310 k: 4.45 / 1.43, 1.24 M: 17.5 / 2.8, 11.2 M: 164.9 / 16.4
-#define LRL_BUILD_LEVELS_FROM (1u << 16)
+#define LRL_BUILD_LEVELS_FROM LRL_LAYOUT_FROM
 
 namespace lrl_build {
 

@@ -16,7 +16,9 @@
 //             charges per lane and per 16-byte piece (tools/probes/l1_gather.hip: 171 CU-cycles for a wave whose lanes
 //             each read their own 64 B from L1) and that, not arithmetic, bounds a one-lane-per-ray traversal: four
 //             children per 64 B halve both the fetches and the chain of dependent trips of a ray.
-//   triHot    4 x float4 per triangle (64 B, one half cache line): plane | p1,k1.x | k1.yz,k2.xy | k2.z
+//             Laid out by lrl_layout_node4 (lrl_build.hip): reachable nodes only, a node's children side by side, subtree after subtree.
+//   triHot    4 x float4 per triangle (64 B, one half cache line): plane | p1,k1.x | k1.yz,k2.xy | k2.z, triangle number
+//   triLeaf   the same records in the order of node4's leaves (a leaf node's triangles side by side): what the four-wide kernels read
 //   triCold   32 B per triangle: uv1 uv2 uv3, material index   (read once per accepted hit)
 //   materials 80-B Color records, de-duplicated on upload (a mesh usually has a handful)
 //   spheres / circles / cylinders / cones / lights: the reference's 128-B / 32-B records as they are
@@ -60,6 +62,7 @@ struct KScene {
     const float4* recs;
     const uint4* node4;      // four-wide compressed nodes, 4 x uint4 each, indexed like recs (FAST lean kernel)
     const float4* triHot;
+    const float4* triLeaf;   // the hot records in the order of node4's leaves (the triangle's number in y of the last quarter); == triHot when the tree is not laid out
     const LrlTriCold* triCold;
     const LrlColor* materials;
     const LrlSphere* spheres;
@@ -130,6 +133,7 @@ enum { LRL_CTR_PRIMARY = 0, LRL_CTR_REFLECT, LRL_CTR_REFRACT, LRL_CTR_SHADOW, LR
 #ifndef LRL_SWARM_CAP
 #define LRL_SWARM_CAP 1024         /* frontier entries of the wave-per-ray continuation kernel (LDS) */
 #endif
+#define LRL_LAYOUT_FROM (1u << 16)    /* device-built trees from this many primitives on are laid out (lrl_layout_node4); = LRL_BUILD_LEVELS_FROM of lrl_build.hip */
 #define LRL_FEEDBACK_ITERS 64u        /* iterations (ray segments) whose hand-over thresholds adapt */
 #define LRL_WORK_COUNTERS 4u         /* per iteration, 128 B apart: sampled work of the hand-over kernels (feedback) */
 #ifndef LRL_GROUP_CAP
@@ -209,8 +213,9 @@ hipError_t lrl_launch_render_fast(const KScene& sc, const KFrame& fr, float4* ou
                                   bool pool, hipStream_t stream);
 hipError_t lrl_launch_decay_origin(const KScene& sc, const LrlTrans* trans, uint32_t stackEntries, bool pool, LrlDecayOrigin* out,
                                    hipStream_t stream);
+// triLeaf / posOfTri: the copy of the hot records in the order of the four-wide tree's leaves, also written when posOfTri != NULL
 hipError_t lrl_launch_triangle_pre(const LrlTriangle* in, const uint32_t* material, uint32_t first, uint32_t count, float4* triHot,
-                                   LrlTriCold* triCold, hipStream_t stream);
+                                   LrlTriCold* triCold, float4* triLeaf, const uint32_t* posOfTri, hipStream_t stream);
 hipError_t lrl_launch_circle_pre(LrlCircle* circles, uint32_t count, hipStream_t stream);
 // Device BVH build (lrl_build.hip): boxes of a staged slab of triangles; scratch size; the build itself (n >= 2 boxes, w of
 // the min corner = primitive bits; writes n records into recs and node4, {height, four-wide height} into info)

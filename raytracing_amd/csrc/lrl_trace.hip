@@ -63,6 +63,11 @@ struct LrlContext {
     uint32_t waterGX = 0, waterGY = 0, waterFirst = 0;
     float waterK = 0, waterDt = 0;
     DevBuf nodes, nodes32, nodes32Loose, triHot, triCold, materials, spheres, circles, cylinders, cones, lights, tex, cube, triStage, matStage;
+    // the four-wide tree as the rays walk it (lrl_layout_node4): nodes32 / nodes32Loose hold the laid-out nodes, triLeaf the hot records in the
+    // order of their leaves, posOfTri where each triangle's record went
+    DevBuf nodes32Raw, layoutScratch, layoutSizes, triLeaf, posOfTri;
+    bool leafOrder = false;        // triLeaf / posOfTri are in use (else the four-wide kernels read triHot itself)
+    uint32_t wideNodes = 0;        // four-wide nodes in use (nodes32)
     uint32_t texW = 0, texH = 0, texL = 0, cubeSize = 0;
     std::vector<LrlColor> materialTable;
     std::unordered_map<ColorKey, uint32_t, ColorHash> materialIndex;
@@ -218,6 +223,7 @@ void fillKScene(const LrlContext* c, KScene& k) {
     k.recs = static_cast<const float4*>(c->nodes.p);
     k.node4 = static_cast<const uint4*>(c->looseInUse ? c->nodes32Loose.p : c->nodes32.p);
     k.triHot = static_cast<const float4*>(c->triHot.p);
+    k.triLeaf = static_cast<const float4*>(c->leafOrder ? c->triLeaf.p : c->triHot.p);
     k.triCold = static_cast<const LrlTriCold*>(c->triCold.p);
     k.materials = static_cast<const LrlColor*>(c->materials.p);
     k.spheres = static_cast<const LrlSphere*>(c->spheres.p);
@@ -438,6 +444,57 @@ std::vector<uint4> buildNode4(const LrlSceneView* s, const FittedBoxes* fitted, 
     return out;
 }
 
+// ---- the four-wide tree in the order the rays walk it (lrl_layout_node4, lrl_build.hip) ----
+// subtree sizes of a host-built four-wide tree by record index: sizes[r] = four-wide nodes, sizes[recCount + r] = triangle leaves (a node's
+// items are records with larger indices: the binary tree is in pre-order)
+void node4Sizes(const std::vector<uint4>& n4, uint32_t recCount, std::vector<uint32_t>& sizes) {
+    sizes.assign(size_t(recCount) * 2, 0u);
+    for (uint32_t r = recCount; r-- > 0;) {
+        const uint32_t refs[4] = {n4[size_t(r) * 4 + 2].z, n4[size_t(r) * 4 + 2].w, n4[size_t(r) * 4 + 3].x, n4[size_t(r) * 4 + 3].y};
+        uint32_t sN = 1, sT = 0;
+        for (uint32_t ref : refs) {
+            if (ref != LRL_REF_NONE && !(ref & LRL_REF_LEAF)) { if (ref > r && ref < recCount) { sN += sizes[ref]; sT += sizes[size_t(recCount) + ref]; } }
+            else if ((ref >> LRL_PRIM_TYPE_SHIFT) == ((LRL_REF_LEAF >> LRL_PRIM_TYPE_SHIFT) | 2u)) ++sT;
+        }
+        sizes[r] = sN; sizes[size_t(recCount) + r] = sT;
+    }
+}
+int ensureLeafOrder(LrlContext* c, uint32_t recCount, uint32_t triCount) {
+    int rc;
+    if ((rc = ensure(c, c->layoutScratch, lrl_layout_scratch_bytes(recCount)))) return rc;
+    if ((rc = ensure(c, c->posOfTri, size_t(triCount) * 4))) return rc;
+    return ensure(c, c->triLeaf, size_t(triCount) * 64);
+}
+void releaseLayoutTemporaries(LrlContext* c) {      // (hipFree waits for the device)
+    if (c->nodes32Raw.bytes > (64u << 20)) release(c->nodes32Raw);
+    if (c->layoutScratch.bytes > (64u << 20)) release(c->layoutScratch);
+    if (c->layoutSizes.bytes > (64u << 20)) release(c->layoutSizes);
+}
+// a host-built four-wide tree (by record index) -> laid out in `dst`; assign: the triangles' places in triLeaf are made anew (posOfTri)
+int layoutFromHost(LrlContext* c, const std::vector<uint4>& node4, uint32_t recCount, uint32_t depth4, DevBuf& dst, bool assign, uint32_t triCount, uint32_t& wideNodes) {
+    std::vector<uint32_t> sizes;
+    node4Sizes(node4, recCount, sizes);
+    if (sizes[size_t(recCount)] > triCount) return fail(c, LRL_ERR_INVALID_ARG, "BVH: a triangle appears in more than one node");
+    int rc;
+    if ((rc = upload(c, c->nodes32Raw, node4.data(), node4.size() * sizeof(uint4)))) return rc;
+    if ((rc = upload(c, c->layoutSizes, sizes.data(), sizes.size() * 4))) return rc;
+    if ((rc = ensureLeafOrder(c, recCount, triCount))) return rc;
+    if ((rc = ensure(c, dst, size_t(sizes[0]) * 64))) return rc;
+    const uint32_t* sz = static_cast<const uint32_t*>(c->layoutSizes.p);
+    // (a caller's tree that names a triangle twice leaves a place of triLeaf without a record: an all-zero record is hit by no ray)
+    if (assign && triCount) HIP_TRY(c, hipMemsetAsync(c->triLeaf.p, 0, size_t(triCount) * 64, c->stream));
+    HIP_TRY(c, lrl_layout_node4(static_cast<const uint4*>(c->nodes32Raw.p), recCount, sz, sz + recCount, depth4 + 2, c->layoutScratch.p, static_cast<uint4*>(dst.p),
+                                static_cast<uint32_t*>(c->posOfTri.p), triCount, assign, c->stream));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));      // `node4` and `sizes` are borrowed only for this call
+    wideNodes = sizes[0];
+    return LRL_OK;
+}
+int gatherTriLeaf(LrlContext* c, uint32_t triCount) {
+    HIP_TRY(c, lrl_launch_tri_leaf_gather(static_cast<const float4*>(c->triHot.p), static_cast<const uint32_t*>(c->posOfTri.p), 0, triCount,
+                                          static_cast<float4*>(c->triLeaf.p), c->stream));
+    return LRL_OK;
+}
+
 // the primitives' own boxes, for buildNode4 (callers' trees); both return whether a primitive left the box it had
 bool ownBoxPut(float* q, const float mn[3], const float mx[3]) {
     bool left = false;
@@ -484,7 +541,8 @@ int runTrianglePre(LrlContext* c, uint32_t first, uint32_t count, const LrlTrian
     rc = upload(c, c->matStage, mat.data(), size_t(count) * 4);
     if (rc) return rc;
     HIP_TRY(c, lrl_launch_triangle_pre(static_cast<const LrlTriangle*>(c->triStage.p), static_cast<const uint32_t*>(c->matStage.p), first,
-                                       count, static_cast<float4*>(c->triHot.p), static_cast<LrlTriCold*>(c->triCold.p), c->stream));
+                                       count, static_cast<float4*>(c->triHot.p), static_cast<LrlTriCold*>(c->triCold.p), static_cast<float4*>(c->triLeaf.p),
+                                       c->leafOrder ? static_cast<const uint32_t*>(c->posOfTri.p) : nullptr, c->stream));
     if (c->deviceBuilt && c->haveScene)      // keep the boxes current for lrl_scene_rebuild_bvh
         HIP_TRY(c, lrl_launch_triangle_boxes(static_cast<const LrlTriangle*>(c->triStage.p), first, count, static_cast<float4*>(c->primMin.p),
                                              static_cast<float4*>(c->primMax.p), c->stream));
@@ -563,8 +621,13 @@ int runDeviceBuild(LrlContext* c, uint32_t prims, uint32_t& recCount, uint32_t& 
     auto asf = [](uint32_t v) { float f; std::memcpy(&f, &v, 4); return f; };
     int rc;
     recCount = std::max(prims, 1u);
+    // large trees are laid out in the order the rays walk them (lrl_layout_node4): built into a temporary by record index, then compacted
+    const bool layout = prims >= LRL_LAYOUT_FROM && c->tuning.treeLayout == 0;
+    DevBuf& raw = layout ? c->nodes32Raw : c->nodes32;
     if ((rc = ensure(c, c->nodes, size_t(recCount) * 64))) return rc;
-    if ((rc = ensure(c, c->nodes32, size_t(recCount) * 64))) return rc;
+    if ((rc = ensure(c, raw, size_t(recCount) * 64))) return rc;
+    c->leafOrder = false;
+    c->wideNodes = recCount;
     if (prims == 1) {      // one primitive: the virtual parent of a leaf
         float4 mn, mx;
         HIP_TRY(c, hipStreamSynchronize(c->stream));      // the boxes may come from a triangle update still in flight (lrl_scene_rebuild_bvh)
@@ -600,17 +663,31 @@ int runDeviceBuild(LrlContext* c, uint32_t prims, uint32_t& recCount, uint32_t& 
     const size_t buildBytes = lrl_build_scratch_bytes(prims);
     if ((rc = ensure(c, c->buildScratch, buildBytes))) return rc;
     if ((rc = ensure(c, c->buildInfo, 256))) return rc;
+    const uint32_t* sizes[2] = {nullptr, nullptr};
     HIP_TRY(c, lrl_build_bvh(static_cast<const float4*>(c->primMin.p), static_cast<const float4*>(c->primMax.p), prims, static_cast<float4*>(c->nodes.p),
-                             static_cast<uint4*>(c->nodes32.p), c->buildScratch.p, buildBytes, static_cast<uint32_t*>(c->buildInfo.p),
-                             c->tuning.deviceBuilder != 1u, c->stream));
-    uint32_t info[3] = {0, 0, 0};
-    HIP_TRY(c, hipMemcpyAsync(info, c->buildInfo.p, 12, hipMemcpyDeviceToHost, c->stream));
+                             static_cast<uint4*>(raw.p), c->buildScratch.p, buildBytes, static_cast<uint32_t*>(c->buildInfo.p),
+                             c->tuning.deviceBuilder != 1u, sizes, c->stream));
+    uint32_t info[5] = {0, 0, 0, 0, 0};
+    HIP_TRY(c, hipMemcpyAsync(info, c->buildInfo.p, 20, hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(c, hipStreamSynchronize(c->stream));
     if (info[2]) return fail(c, LRL_ERR_INVALID_ARG, "a primitive has a coordinate that is not finite (NaN or infinity): no tree can bound it");
     if (info[0] == 0 || info[1] == 0) return fail(c, LRL_ERR_DEVICE, "device BVH build did not reach the root");
     if (info[0] + 1 > LRL_MAX_BVH_DEPTH) return fail(c, LRL_ERR_BVH_DEPTH, "device-built BVH deeper than LRL_MAX_BVH_DEPTH");
     depth = info[0];
     c->node4Depth = info[1];
+    if (layout) {
+        const uint32_t triCount = c->num.triangleNum;
+        if (!sizes[0] || info[3] == 0 || info[3] > recCount || info[4] > triCount) return fail(c, LRL_ERR_DEVICE, "device BVH build: the four-wide subtree sizes are not what a tree over these primitives has");
+        if ((rc = ensure(c, c->nodes32, size_t(info[3]) * 64))) return rc;
+        if ((rc = ensureLeafOrder(c, recCount, triCount))) return rc;
+        HIP_TRY(c, lrl_layout_node4(static_cast<const uint4*>(raw.p), recCount, sizes[0], sizes[1], info[1] + 1, c->layoutScratch.p, static_cast<uint4*>(c->nodes32.p),
+                                    static_cast<uint32_t*>(c->posOfTri.p), triCount, true, c->stream));
+        if ((rc = gatherTriLeaf(c, triCount))) return rc;
+        c->leafOrder = true;
+        c->wideNodes = info[3];
+        HIP_TRY(c, hipStreamSynchronize(c->stream));
+        releaseLayoutTemporaries(c);
+    }
     if (buildBytes > (64u << 20)) release(c->buildScratch);      // the tree is built: only the records stay (small scratch is kept for rebuilds)
     return LRL_OK;
 }
@@ -640,7 +717,7 @@ LrlTuning defaultTuning() {
     LrlTuning t{};
     t.handoverEarly = LRL_HANDOVER_AUTO; t.handoverLate = LRL_HANDOVER_AUTO; t.handoverListLen = 0;
     t.adapt = 1; t.groupLanes = 0; t.contSlots = 0; t.groupCapX = 0; t.sparseFrom = 5; t.compactFrom = -1; t.coopFetch = 0; t.groupQuad = 0; t.streamWords = 0; t.refillMin = 16; t.phasedTrips = 0; t.deviceBuilder = 0;
-    t.workLow = 12.0f; t.pollLag = 1; t.traceRef = 0; t.batchSlots = 0; t.debug = 0; t.deterministic = 0;
+    t.workLow = 12.0f; t.pollLag = 1; t.traceRef = 0; t.batchSlots = 0; t.debug = 0; t.treeLayout = 0; t.deterministic = 0;
     return t;
 }
 
@@ -723,7 +800,7 @@ int lrl_set_tuning(LrlContext* c, const LrlTuning* t) {
     if (t->phasedTrips > 2) return fail(c, LRL_ERR_INVALID_ARG, "phasedTrips must be 0 (by launch size), 1 (on) or 2 (off)");
     if (t->deviceBuilder > 2) return fail(c, LRL_ERR_INVALID_ARG, "deviceBuilder must be 0 (PLOC), 1 (LBVH) or 2 (PLOC)");
     if (t->streamWords > 4096 || t->refillMin > 64) return fail(c, LRL_ERR_INVALID_ARG, "streamWords <= 4096, refillMin <= 64");
-    if (t->deterministic > 1) return fail(c, LRL_ERR_INVALID_ARG, "deterministic must be 0 or 1");
+    if (t->deterministic > 1 || t->treeLayout > 1) return fail(c, LRL_ERR_INVALID_ARG, "deterministic and treeLayout must be 0 or 1");
     c->tuning = *t;
     c->phasedTrial.state = 0; c->phasedTrial.signature = 0;
     c->handoverThr.clear();      // the adaptive thresholds start again from the new base values
@@ -740,7 +817,7 @@ int lrl_destroy(LrlContext* c) {
     // writes its feedback into the pinned words
     if (c->renderedOnce && c->evLastRender) (void)hipEventSynchronize(c->evLastRender);
     if (c->evCont) (void)hipEventSynchronize(c->evCont);
-    for (DevBuf* b : {&c->primMin, &c->primMax, &c->buildScratch, &c->buildInfo, &c->waterPoints, &c->waterTris, &c->waterMat, &c->nodes, &c->nodes32, &c->nodes32Loose, &c->triHot, &c->triCold, &c->materials, &c->spheres, &c->circles, &c->cylinders, &c->cones, &c->lights,
+    for (DevBuf* b : {&c->nodes32Raw, &c->layoutScratch, &c->layoutSizes, &c->triLeaf, &c->posOfTri, &c->primMin, &c->primMax, &c->buildScratch, &c->buildInfo, &c->waterPoints, &c->waterTris, &c->waterMat, &c->nodes, &c->nodes32, &c->nodes32Loose, &c->triHot, &c->triCold, &c->materials, &c->spheres, &c->circles, &c->cylinders, &c->cones, &c->lights,
                       &c->tex, &c->cube, &c->triStage, &c->matStage, &c->transDev, &c->outDev, &c->hitDev, &c->counterDev, &c->decayDev, &c->timelineDev, &c->wfArena})
         release(*b);
     for (auto& e : c->timingEvents) { (void)hipEventDestroy(e.first); (void)hipEventDestroy(e.second); }
@@ -810,22 +887,35 @@ static int uploadCallerTree(LrlContext* c, const LrlSceneView* s, uint32_t& recC
     const size_t tightened = fit ? fitted.count : 0;
     fitted = FittedBoxes();
     c->node4Depth = depth4;
-    rc = upload(c, c->nodes32, node4.data(), node4.size() * sizeof(uint4));
-    if (rc) return rc;
-    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    const uint32_t triCount = s->num.triangleNum;
+    const bool layout = c->tuning.treeLayout == 0;
+    if (layout) {
+        if ((rc = layoutFromHost(c, node4, recCount, depth4, c->nodes32, true, triCount, c->wideNodes))) return rc;
+    } else {
+        if ((rc = upload(c, c->nodes32, node4.data(), node4.size() * sizeof(uint4)))) return rc;
+        HIP_TRY(c, hipStreamSynchronize(c->stream));
+        c->wideNodes = recCount;
+    }
+    c->leafOrder = layout;
     c->haveLoose = c->looseInUse = false;
     c->parkedTight = uint32_t(tightened);
     if (fit) {      // the same tree with the caller's boxes, for when the primitives move under it (ownBoxesStale)
         node4 = buildNode4(s, nullptr, recOf, recCount, depth4);
         c->node4Depth = std::max(c->node4Depth, depth4);      // (the stacks are sized for either copy)
-        rc = upload(c, c->nodes32Loose, node4.data(), node4.size() * sizeof(uint4));
-        if (rc) return rc;
-        HIP_TRY(c, hipStreamSynchronize(c->stream));
+        uint32_t looseNodes = 0;
+        if (layout) {
+            if ((rc = layoutFromHost(c, node4, recCount, depth4, c->nodes32Loose, false, triCount, looseNodes))) return rc;      // (the triangles keep the places the fitted tree gave them)
+        } else {
+            if ((rc = upload(c, c->nodes32Loose, node4.data(), node4.size() * sizeof(uint4)))) return rc;
+            HIP_TRY(c, hipStreamSynchronize(c->stream));
+        }
         c->haveLoose = true;
         if (c->callerTree.data() != s->bvh) c->callerTree.assign(s->bvh, s->bvh + s->bvhNodeNum);
     } else if (c->callerTree.data() != s->bvh) { c->callerTree.clear(); c->callerTree.shrink_to_fit(); }
     c->pathsAtRest = 0;
-    if (c->tuning.debug) std::fprintf(stderr, "lrl: the four-wide tree bounds %zu primitives by their own boxes\n", tightened);
+    node4 = std::vector<uint4>();
+    releaseLayoutTemporaries(c);
+    if (c->tuning.debug) std::fprintf(stderr, "lrl: the four-wide tree bounds %zu primitives by their own boxes; %u of %u node slots in use\n", tightened, c->wideNodes, recCount);
     return LRL_OK;
 }
 
@@ -858,9 +948,13 @@ static int refitAtRest(LrlContext* c, uint64_t paths) {
     if (!fitOwnBoxes(&v, c->ownBox, fitted)) { c->pathsAtRest = 0; c->callerTree.clear(); c->callerTree.shrink_to_fit(); return LRL_OK; }      // (nothing to gain any more)
     uint32_t depth4 = 0;
     std::vector<uint4> node4 = buildNode4(&v, &fitted, recOf, recCount, depth4);
-    int rc = upload(c, c->nodes32, node4.data(), node4.size() * sizeof(uint4));
+    int rc;
+    if (c->leafOrder) rc = layoutFromHost(c, node4, recCount, depth4, c->nodes32, false, c->num.triangleNum, c->wideNodes);      // (the triangles stay where they are in triLeaf)
+    else {
+        rc = upload(c, c->nodes32, node4.data(), node4.size() * sizeof(uint4));
+        if (!rc) HIP_TRY(c, hipStreamSynchronize(c->stream));
+    }
     if (rc) return rc;
-    HIP_TRY(c, hipStreamSynchronize(c->stream));
     c->node4Depth = std::max(c->node4Depth, depth4);
     c->parkedTight = uint32_t(fitted.count);
     c->looseInUse = false;
@@ -901,6 +995,7 @@ int lrl_scene_upload(LrlContext* c, const LrlSceneView* s) {
     if (deviceBuild) { c->callerTree.clear(); c->callerTree.shrink_to_fit(); }
     c->haveLoose = c->looseInUse = false;
     c->parkedTight = 0;
+    c->leafOrder = false;      // (the device build lays its tree out after the triangles are there; a caller's tree before: TrianglePre then writes both copies)
     if (!deviceBuild) {
         if (g.triangleNum && s->trianglesOrigin) {
             c->ownBox.assign(size_t(g.triangleNum) * 6, 0.0f);
@@ -949,7 +1044,8 @@ int lrl_scene_upload(LrlContext* c, const LrlSceneView* s) {
                 hot[size_t(i) * 4 + 0] = make_float4(t.plane[0], t.plane[1], t.plane[2], t.plane[3]);
                 hot[size_t(i) * 4 + 1] = make_float4(t.p1[0], t.p1[1], t.p1[2], t.k1[0]);
                 hot[size_t(i) * 4 + 2] = make_float4(t.k1[1], t.k1[2], t.k2[0], t.k2[1]);
-                hot[size_t(i) * 4 + 3] = make_float4(t.k2[2], 0, 0, 0);
+                float id; std::memcpy(&id, &i, 4);
+                hot[size_t(i) * 4 + 3] = make_float4(t.k2[2], id, 0, 0);      // (the triangle's number travels in its hot record)
                 LrlTriCold& q = cold[i];
                 std::memcpy(q.uv1, t.uv1, 8); std::memcpy(q.uv2, t.uv2, 8); std::memcpy(q.uv3, t.uv3, 8);
                 q.material = internMaterial(c, t.color); q._pad = 0;
@@ -960,6 +1056,7 @@ int lrl_scene_upload(LrlContext* c, const LrlSceneView* s) {
             if (rc) return rc;
             rc = upload(c, c->materials, c->materialTable.data(), c->materialTable.size() * sizeof(LrlColor));
             if (rc) return rc;
+            if (c->leafOrder && (rc = gatherTriLeaf(c, g.triangleNum))) return rc;
             HIP_TRY(c, hipStreamSynchronize(c->stream));
         }
     }
@@ -1042,7 +1139,8 @@ int lrl_scene_update_triangles_noalloc(LrlContext* c, uint32_t first, uint32_t c
     // the area keeps the last call's records beyond `count`: nothing reads them, the kernels stop at `count`
     HIP_TRY(c, hipMemcpyAsync(stageTris, pinTris, size_t(count) * sizeof(LrlTriangle), hipMemcpyHostToDevice, c->stream));
     HIP_TRY(c, hipMemcpyAsync(stageMat, pinMat, size_t(count) * 4, hipMemcpyHostToDevice, c->stream));
-    HIP_TRY(c, lrl_launch_triangle_pre(stageTris, stageMat, first, count, static_cast<float4*>(c->triHot.p), static_cast<LrlTriCold*>(c->triCold.p), c->stream));
+    HIP_TRY(c, lrl_launch_triangle_pre(stageTris, stageMat, first, count, static_cast<float4*>(c->triHot.p), static_cast<LrlTriCold*>(c->triCold.p),
+                                       static_cast<float4*>(c->triLeaf.p), c->leafOrder ? static_cast<const uint32_t*>(c->posOfTri.p) : nullptr, c->stream));
     if (c->deviceBuilt)      // keep the boxes current for lrl_scene_rebuild_bvh
         HIP_TRY(c, lrl_launch_triangle_boxes(stageTris, first, count, static_cast<float4*>(c->primMin.p), static_cast<float4*>(c->primMax.p), c->stream));
     HIP_TRY(c, hipStreamSynchronize(c->stream));   // the caller's array is borrowed only for this call; the staging area is free again
@@ -1111,6 +1209,7 @@ int lrl_scene_update_bvh(LrlContext* c, const LrlBVHNode* bvh, uint32_t bvhNodeN
     HIP_TRY(c, hipStreamSynchronize(c->stream));      // frames in flight walk the old tree
     c->haveScene = false;                             // (a failed upload leaves no half-written tree in use)
     if ((rc = uploadCallerTree(c, &v, recCount))) return rc;
+    if (c->leafOrder && (rc = gatherTriLeaf(c, c->num.triangleNum))) return rc;      // the new tree has its own order of leaves
     c->nodeNum = bvhNodeNum; c->recNum = recCount; c->bvhDepth = depth;
     c->handoverThr.clear(); c->feedbackTick = 0; c->contIters = 0;
     c->phasedTrial.state = 0; c->phasedTrial.signature = 0;
@@ -1834,7 +1933,8 @@ int lrl_water_step(LrlContext* c, uint32_t substeps) {
     HIP_TRY(c, lrl_launch_water_run(static_cast<float4*>(c->waterPoints.p), c->waterGX, c->waterGY, c->waterK, c->waterDt, substeps,
                                     static_cast<LrlTriangle*>(c->waterTris.p), c->stream));
     HIP_TRY(c, lrl_launch_triangle_pre(static_cast<const LrlTriangle*>(c->waterTris.p), static_cast<const uint32_t*>(c->waterMat.p), c->waterFirst, count,
-                                       static_cast<float4*>(c->triHot.p), static_cast<LrlTriCold*>(c->triCold.p), c->stream));
+                                       static_cast<float4*>(c->triHot.p), static_cast<LrlTriCold*>(c->triCold.p), static_cast<float4*>(c->triLeaf.p),
+                                       c->leafOrder ? static_cast<const uint32_t*>(c->posOfTri.p) : nullptr, c->stream));
     if (c->deviceBuilt)      // keep the boxes current for lrl_scene_rebuild_bvh
         HIP_TRY(c, lrl_launch_triangle_boxes(static_cast<const LrlTriangle*>(c->waterTris.p), c->waterFirst, count, static_cast<float4*>(c->primMin.p),
                                              static_cast<float4*>(c->primMax.p), c->stream));
@@ -1857,6 +1957,7 @@ int lrl_scene_info(const LrlContext* c, LrlSceneInfo* out) {
     out->bvhNodes = c->nodeNum; out->bvhRecords = c->recNum; out->bvhDepth = c->bvhDepth; out->wideDepth = c->node4Depth;
     out->deviceBuilt = c->deviceBuilt ? 1u : 0u; out->materials = uint32_t(c->materialTable.size());
     out->ownBoxes = c->looseInUse ? 0u : c->parkedTight;
+    out->wideNodes = c->wideNodes; out->leafOrder = c->leafOrder ? 1u : 0u;
     return LRL_OK;
 }
 
@@ -1868,8 +1969,8 @@ int lrl_last_render_info(const LrlContext* c, LrlRenderInfo* out) {
 
 int lrl_scene_device_bytes(LrlContext* c, uint64_t out[4]) {
     if (!c || !out) return LRL_ERR_INVALID_ARG;
-    out[0] = uint64_t(c->recNum) * 128;      // binary records + four-wide compressed nodes, 64 B each per inner node
-    out[1] = uint64_t(c->num.triangleNum) * 64;
+    out[0] = uint64_t(c->recNum) * 64 + uint64_t(c->wideNodes) * 64 * (c->haveLoose ? 2 : 1);      // binary records + the four-wide nodes in use (two copies where a caller's tree is fitted)
+    out[1] = uint64_t(c->num.triangleNum) * 64 * (c->leafOrder ? 2 : 1);      // hot records by triangle number (+ the copy in leaf order)
     out[2] = uint64_t(c->num.triangleNum) * sizeof(LrlTriCold) + c->materialTable.size() * sizeof(LrlColor);
     out[3] = uint64_t(c->num.sphereNum + c->num.circleNum + c->num.cylinderNum + c->num.coneNum) * 128 + uint64_t(c->num.pointLightNum) * 32 +
              uint64_t(c->texW) * c->texH * c->texL * 4 + uint64_t(c->cubeSize) * c->cubeSize * 24;

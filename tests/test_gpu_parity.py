@@ -1281,3 +1281,51 @@ def test_scene_changes_and_renders_on_a_callers_stream_are_ordered(pool_model):
     for i in range(4):
         assert np.array_equal(frames["blocking"][i].view(np.uint32), frames["foreign stream"][i].view(np.uint32)), i
     assert not np.array_equal(frames["blocking"][0], frames["blocking"][3])      # the water did move
+
+
+def test_tree_layout_changes_nothing(default_model, bunny0_model, pool_model):
+    """The four-wide tree is stored in the order the rays walk it (LrlTuning.treeLayout = 0: reachable nodes only, a node's children side by
+    side, subtree after subtree; the triangles' hot records in the order of the leaves, their numbers inside the records) or as built,
+    addressed by binary record index (1).  Where a record lies decides nothing: FAST frames and hit ids are the same bit for bit, for a
+    caller's tree (every primitive class, the Pool's fitted + loose pair, the bunny) and for a tree the library built (the bunny: 77 560
+    triangles, laid out from 65 536 on), also after triangles were updated in place (both copies of their records follow), after a new
+    caller's tree (lrl_scene_update_bvh) and after a rebuild.  SceneInfo says what is in use."""
+    from raytracing_amd import tracer as T
+    cases = [("default", default_model, "bvh_viewB_256", False), ("bunny", bunny0_model, "mesh_bunny0_240x135_depth4", False),
+             ("pool", pool_model, "pool_viewB_192", False), ("bunny, library's tree", bunny0_model, "mesh_bunny0_240x135_depth4", True)]
+    for what, model, name, device in cases:
+        g = load_golden(name)
+        out = {}
+        for layout in (0, 1):
+            t = T.Tracer(0)
+            try:
+                t.set_tuning(treeLayout=layout)
+                t.scene_upload(without_tree(model) if device else model.scene_view())
+                t.set_camera(g["trans"], g["width"], g["height"])
+                t.set_decay_origin((0, 0, 0, 1))
+                info = t.scene_info()
+                assert info["leafOrder"] == (1 - layout) and (info["wideNodes"] < info["bvhRecords"]) == (layout == 0), (what, layout, info)
+                frames = [t.render(max_depth=g["depth"], variant=g["variant"], mode=abi.MODE_FAST)]
+                tris = model.arrays()["triangles"]
+                n = min(len(tris), 3000)
+                moved = tris[:n].copy()
+                for f in ("p1", "p2", "p3"):
+                    moved[f][:, 2] += np.float32(0.01)
+                t.update_triangles(0, moved)                               # in place: both copies of the hot records follow
+                if device:
+                    t.rebuild_bvh()
+                frames.append(t.render(max_depth=g["depth"], variant=g["variant"], mode=abi.MODE_FAST))
+                t.update_triangles(0, tris[:n])
+                if device:
+                    t.rebuild_bvh()
+                else:
+                    v = model.scene_view()
+                    t.update_bvh(v.bvh, v.bvhNodeNum)                      # the same tree again, through the update path
+                frames.append(t.render(max_depth=g["depth"], variant=g["variant"], mode=abi.MODE_FAST))
+                out[layout] = frames
+            finally:
+                t.close()
+        for i, (a, b) in enumerate(zip(out[0], out[1])):
+            assert np.array_equal(a[0].view(np.uint32), b[0].view(np.uint32)) and np.array_equal(a[1], b[1]), (what, i)
+        assert np.array_equal(out[0][0][0].view(np.uint32), out[0][2][0].view(np.uint32)), what          # back where it started
+        assert not np.array_equal(out[0][0][0], out[0][1][0]), what                                       # the move was seen
