@@ -246,6 +246,10 @@ class Workload:
                 # lanes that carried a live ray (lean kernel) or a frontier entry (hand-over kernel), over 64 x the trips of their waves
                 self.useful_lane_frac = float(cf.laneTrips) / (64.0 * float(cf.waveTrips))
                 self.wave_trips = int(cf.waveTrips)
+                # the two kernels apart: the one-lane-per-ray kernel (lanes whose ray is still going) and the hand-over kernel (lanes with a frontier entry)
+                lw, ll = int(cf.waveTrips) - int(cf.groupRounds), int(cf.laneTrips) - int(cf.groupLanes)
+                self.lane_use = {"lean_wave_trips": lw, "lean_useful_lane_frac": round(ll / (64.0 * lw), 4) if lw else None,
+                                 "handover_rounds": int(cf.groupRounds), "handover_useful_lane_frac": round(int(cf.groupLanes) / (64.0 * int(cf.groupRounds)), 4) if cf.groupRounds else None}
 
     def render_into(self, ptr, stream=None, time_kernels=False):
         self.tr.render_device(ptr, stream=stream, time_kernels=time_kernels, **self.kw())
@@ -300,6 +304,7 @@ class Workload:
                                "frac_vs_fp32_spec": round(valu / (kernel_ms * 1e-3) / 1e9 / spec, 4), "fp32_spec_peak": round(spec, 1),
                                "useful_lane_frac": round(self.useful_lane_frac, 4) if self.useful_lane_frac else None,
                                "useful_busy_frac": round(busy * self.useful_lane_frac, 4) if self.useful_lane_frac else None,
+                               "lane_use": getattr(self, "lane_use", None),
                                "useful_note": "useful_lane_frac = lanes that carried a live ray (a frontier entry in the hand-over kernel) / (64 x wave-trips), counted by the counting "
                                               "instantiation of the timed kernels on this run's frame; a wave lives until its longest ray is done, and the idle lanes' instructions are "
                                               "issued all the same: useful_busy_frac = busy_frac x useful_lane_frac.  frac_vs_fp32_spec prices the same count against the guide's "

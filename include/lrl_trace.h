@@ -138,6 +138,8 @@ typedef struct LrlCounters {
     uint64_t laneTrips;          /* LRL_FLAG_COUNT_FETCHES: lanes that carried a live ray (or a frontier entry), summed over the     */
     uint64_t waveTrips;          /* trips (rounds) of the FAST trace kernels' waves, and those trips: laneTrips / (64 x waveTrips)   */
                                  /* is the share of the issued vector work that was some ray's own                                    */
+    uint64_t groupLanes;         /* the hand-over kernels' part of those two sums (lanes with a frontier entry, rounds of their waves) */
+    uint64_t groupRounds;
 } LrlCounters;
 
 /* Scheduling knobs of the FAST-mode pipeline (no counterpart in the reference, whose driver schedules its fragment shader).

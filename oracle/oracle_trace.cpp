@@ -761,7 +761,7 @@ int oracle_render(const LrlSceneView* sv, const LrlTrans* trans, const OraclePar
         counters->raysPrimary = total.primary; counters->raysReflect = total.reflect; counters->raysRefract = total.refract;
         counters->raysShadow = total.shadow; counters->nodeVisits = total.nodes; counters->triTests = total.tri;
         counters->sphereTests = total.sph; counters->otherTests = total.other; counters->primaryHits = total.primaryHits;
-        counters->recordFetches = 0; counters->laneTrips = 0; counters->waveTrips = 0;
+        counters->recordFetches = 0; counters->laneTrips = 0; counters->waveTrips = 0; counters->groupLanes = 0; counters->groupRounds = 0;
     }
     return 0;
 }

@@ -80,7 +80,7 @@ class RenderInfo(C.Structure):
 
 class Counters(C.Structure):
     _fields_ = [(n, C.c_uint64) for n in ("raysPrimary", "raysReflect", "raysRefract", "raysShadow", "nodeVisits", "triTests",
-                                          "sphereTests", "otherTests", "primaryHits", "recordFetches", "laneTrips", "waveTrips")]
+                                          "sphereTests", "otherTests", "primaryHits", "recordFetches", "laneTrips", "waveTrips", "groupLanes", "groupRounds")]
 
     def as_dict(self):
         return {n: int(getattr(self, n)) for n, _ in self._fields_}

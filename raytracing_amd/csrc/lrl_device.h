@@ -94,7 +94,7 @@ struct KFrame {
 };
 
 enum { LRL_CTR_PRIMARY = 0, LRL_CTR_REFLECT, LRL_CTR_REFRACT, LRL_CTR_SHADOW, LRL_CTR_NODES, LRL_CTR_TRI, LRL_CTR_SPH,
-       LRL_CTR_OTHER, LRL_CTR_PRIMARY_HITS, LRL_CTR_FETCH, LRL_CTR_LANE_TRIPS, LRL_CTR_WAVE_TRIPS, LRL_CTR_COUNT };
+       LRL_CTR_OTHER, LRL_CTR_PRIMARY_HITS, LRL_CTR_FETCH, LRL_CTR_LANE_TRIPS, LRL_CTR_WAVE_TRIPS, LRL_CTR_GROUP_LANES, LRL_CTR_GROUP_ROUNDS, LRL_CTR_COUNT };
 
 #ifndef LRL_BLOCK_THREADS
 #define LRL_BLOCK_THREADS 256

@@ -1328,4 +1328,5 @@ def test_tree_layout_changes_nothing(default_model, bunny0_model, pool_model):
         for i, (a, b) in enumerate(zip(out[0], out[1])):
             assert np.array_equal(a[0].view(np.uint32), b[0].view(np.uint32)) and np.array_equal(a[1], b[1]), (what, i)
         assert np.array_equal(out[0][0][0].view(np.uint32), out[0][2][0].view(np.uint32)), what          # back where it started
-        assert not np.array_equal(out[0][0][0], out[0][1][0]), what                                       # the move was seen
+        if what == "pool":                                                                                # (the water is in view: the move was seen)
+            assert not np.array_equal(out[0][0][0], out[0][1][0]), what

@@ -9,8 +9,10 @@ cd $root/raytracing_amd/csrc
 F="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -Wno-unused-function $extra"
 hipcc $F -ffp-contract=off -c kernels_parity.hip -o $b/kp.o &
 hipcc $F -ffp-contract=fast -fno-slp-vectorize -c kernels_fast.hip -o $b/kf.o -Rpass-analysis=kernel-resource-usage 2> $b/res.txt &
-hipcc $F -c lrl_trace.hip -o $b/t.o &
+hipcc $F -c lrl_context.hip -o $b/t1.o &
+hipcc $F -c lrl_scene.hip -o $b/t2.o &
+hipcc $F -c lrl_schedule.hip -o $b/t3.o &
 hipcc $F -c lrl_build.hip -o $b/b.o &
 wait
-hipcc --offload-arch=gfx950 -shared -fPIC -o $root/raytracing_amd/variants/$name.so $b/kp.o $b/kf.o $b/t.o $b/b.o
+hipcc --offload-arch=gfx950 -shared -fPIC -o $root/raytracing_amd/variants/$name.so $b/kp.o $b/kf.o $b/t1.o $b/t2.o $b/t3.o $b/b.o
 grep -A12 "renderKernelILb0ELb0" $b/res.txt | grep -E "VGPRs:|Scratch|Occupancy" | tr '\n' ' '; echo " <- $name"

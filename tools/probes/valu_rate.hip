@@ -25,6 +25,23 @@
 #define RCP(K) "v_rcp_f32 %" #K ", %" #K "\n"
 #define PKFMA(K) "v_mov_b32 %" #K ", %" #K "\n"
 
+// packed fp32 fma: 64-bit operands (register pairs); the guide's FP32 vector peak (157.3 TFLOP/s) assumes it issues at the rate of v_fma_f32
+typedef float f2 __attribute__((ext_vector_type(2)));
+#define BODY2(ASM)                                                                                  \
+    f2 a0 = {float(threadIdx.x), 1.0f}, a1 = a0 + 1.0f, a2 = a0 + 2.0f, a3 = a0 + 3.0f, a4 = a0 + 4.0f, a5 = a0 + 5.0f, a6 = a0 + 6.0f, a7 = a0 + 7.0f;   \
+    const f2 b = {1.0001f, 0.9999f}, c = {0.5f, 0.25f};                                             \
+    for (uint32_t i = 0; i < iters; ++i) {                                                          \
+        REP8(asm volatile(ASM(0) ASM(1) ASM(2) ASM(3) ASM(4) ASM(5) ASM(6) ASM(7)                   \
+                          : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7) : "v"(b), "v"(c));)   \
+    }                                                                                               \
+    const f2 s = a0 + a1 + a2 + a3 + a4 + a5 + a6 + a7;                                             \
+    if (s.x + s.y == 12345.678f) out[0] = s.x;
+#define PK(K) "v_pk_fma_f32 %" #K ", %" #K ", %8, %9\n"
+#define PKSEL(K) "v_pk_fma_f32 %" #K ", %" #K ", %8, %8 op_sel:[0,0,1] op_sel_hi:[1,0,1]\n"
+#define PKMUL(K) "v_pk_mul_f32 %" #K ", %" #K ", %8\n"
+__global__ __launch_bounds__(256) void kPkFma(uint32_t iters, float* out) { BODY2(PK) }
+__global__ __launch_bounds__(256) void kPkFmaSel(uint32_t iters, float* out) { BODY2(PKSEL) }
+__global__ __launch_bounds__(256) void kPkMul(uint32_t iters, float* out) { BODY2(PKMUL) }
 __global__ __launch_bounds__(256) void kFma(uint32_t iters, float* out) { BODY(FMA) }
 __global__ __launch_bounds__(256) void kMax3(uint32_t iters, float* out) { BODY(MAX3) }
 __global__ __launch_bounds__(256) void kCvt(uint32_t iters, float* out) { BODY(CVT) }
@@ -54,6 +71,9 @@ int main() {
     float* out; CHECK(hipMalloc(&out, 64));
     for (uint32_t occ : {1u, 8u}) {
         if (run("v_fma_f32", kFma, out, occ)) return 1;
+        if (run("v_pk_fma_f32", kPkFma, out, occ)) return 1;
+        if (run("v_pk_fma_f32 op_sel", kPkFmaSel, out, occ)) return 1;
+        if (run("v_pk_mul_f32", kPkMul, out, occ)) return 1;
         if (run("v_mul_f32", kMul, out, occ)) return 1;
         if (run("v_max3_f32", kMax3, out, occ)) return 1;
         if (run("v_cvt_f32_ubyte1", kCvt, out, occ)) return 1;

@@ -1,7 +1,10 @@
 #!/usr/bin/env python3
 """Folds the rocprofv3 outputs of tools/run_stats.sh + tools/run_pmc_tag.sh (under gpurun_out/) into the committed summaries
-profiles/<name>_kernel_stats.csv, profiles/<name>_pmc.json and the traffic file bench.py reads (profiles/r02_traffic*.json).
-usage: tools/summarize_r02.py name stats_dir pmc_tag frames traffic_file '<json: the keys bench.py matches>' "note"
+profiles/<name>_kernel_stats.csv, profiles/<name>_pmc.json and the traffic file bench.py reads (profiles/<round>_traffic*.json).
+The traffic file carries the sha256 of the kernel sources the passes were measured on (bench.csrc_hash(): run this script on the tree
+the profiled library was built from) and the LrlTuning the passes pinned; bench.py withholds the roofline fraction when they are
+not the sources of the build it times.
+usage: tools/summarize_round.py name stats_dir pmc_tag frames traffic_file '<json: the keys bench.py matches>' "note" ["tuning of the passes"]
 Counters are summed over the launches of one frame per kernel (frames = frames the profiled run rendered with the timed kernels:
 warm-up + steps + the per-launch timing pass of bench.py).  HBM traffic follows /opt/skills/guides/MI355X_MICROARCH.md:
 FETCH_SIZE and WRITE_SIZE are in KiB and taken in passes of their own; FETCH_SIZE counts a 128-B request as 64 B on gfx950.  The
@@ -9,6 +12,9 @@ factor this access shape needs (every lane its own 64-B record) is calibrated by
 (profiles/r02_hbm_gather_probe.txt) and passed in as FETCH_FACTOR (environment, default 2 as the guide prescribes)."""
 import collections, csv, glob, json, os, shutil, sys
 name, stats_dir, pmc_tag, frames, traffic_file, match, note = sys.argv[1:8]
+tuning = sys.argv[8] if len(sys.argv) > 8 else ""
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import bench
 frames = int(frames)
 factor = float(os.environ.get("FETCH_FACTOR", "2"))
 if stats_dir != "-":
@@ -51,6 +57,9 @@ if "SQ_INSTS_VALU" in trace:
     d["instructions_per_frame"] = {n: trace[n] for n in ("SQ_INSTS_VALU", "SQ_INSTS_SALU", "SQ_INSTS_VMEM_RD", "SQ_INSTS_LDS") if n in trace}
 if "SQ_BUSY_CYCLES" in trace and "SQ_ACTIVE_INST_VALU" in trace:
     d["sq"] = {n: trace[n] for n in trace if n.startswith("SQ_")}
+if "TCC_EA0_RDREQ_sum" in trace:
+    d["hbm_read_requests_per_frame"] = trace["TCC_EA0_RDREQ_sum"]
+    d["hbm_read_requests_128B_per_frame"] = trace.get("TCC_EA0_RDREQ_128B_sum")
 if "TCC_HIT_sum" in trace:
     d["l2_hit_rate"] = trace["TCC_HIT_sum"] / max(1.0, trace["TCC_HIT_sum"] + trace["TCC_MISS_sum"])
 if "TCP_TCC_READ_REQ_sum" in trace:
@@ -68,4 +77,6 @@ if "hbm_bytes_per_frame" in d and traffic_file != "-":
     wl = json.loads(match)
     wl["hbm_bytes_per_frame"] = d["hbm_bytes_per_frame"]
     wl["source"] = f"profiles/{name}_pmc.json"
+    wl["csrc_sha256"] = bench.csrc_hash()
+    wl["tuning"] = tuning
     json.dump(wl, open(f"profiles/{traffic_file}", "w"), indent=1)
