@@ -1,5 +1,5 @@
 // Device-side scene layout and kernel launch interface shared by the C-ABI implementation
-// (lrl_trace.hip) and the two kernel translation units (kernels_parity.hip, kernels_fast.hip).
+// (lrl_context.hip, lrl_scene.hip, lrl_schedule.hip) and the two kernel translation units (kernels_parity.hip, kernels_fast.hip).
 //
 // HBM layout (built by lrl_scene_upload from the reference's AoS records):
 //   recs      4 x float4 per INNER node (64 B, one half cache line), boxes of both children in the parent:
@@ -11,7 +11,7 @@
 //             dropped: traversal keeps a per-lane stack of pending far children in LDS instead of the
 //             reference's parent-pointer trail.
 //   node4     4 x uint4 per node of the four-wide collapse of the same tree (64 B), child boxes as bytes relative to the
-//             node's origin and power-of-two units (layout at buildNode4, lrl_trace.hip); indexed by the record index of
+//             node's origin and power-of-two units (layout at buildNode4, lrl_scene.hip); indexed by the record index of
 //             the binary node it replaces, so refs are shared with `recs`.  FAST lean kernel only.  Why: the vector L1
 //             charges per lane and per 16-byte piece (tools/probes/l1_gather.hip: 171 CU-cycles for a wave whose lanes
 //             each read their own 64 B from L1) and that, not arithmetic, bounds a one-lane-per-ray traversal: four
