@@ -1330,3 +1330,44 @@ def test_tree_layout_changes_nothing(default_model, bunny0_model, pool_model):
         assert np.array_equal(out[0][0][0].view(np.uint32), out[0][2][0].view(np.uint32)), what          # back where it started
         if what == "pool":                                                                                # (the water is in view: the move was seen)
             assert not np.array_equal(out[0][0][0], out[0][1][0]), what
+
+
+def test_deterministic_mode_decides_nothing_from_measurements(pool_model):
+    """LrlTuning.deterministic = 1: no timed trial of triangle trips, no adaptation of the hand-over thresholds, no refit of a moved scene at
+    rest: every frame of a scene issues the same launches.  Twelve frames in a row report the base thresholds, trialState 0 and triangle
+    trips off, and give the adaptive mode's frame bit for bit; after a water step the caller's boxes stay in use however many frames follow."""
+    from raytracing_amd import tracer as T
+    g = load_golden("pool_viewB_192")
+    gx, gy = scenes.POOL_GRID
+    k, dt = scenes.POOL_WATER
+    nw = 2 * (gx - 1) * (gy - 1)
+    tris = pool_model.arrays()["triangles"]
+    w0 = scenes.pool_water_points(pool_model)
+    jit = host.jitter_table(16)
+    kw = dict(max_depth=8, variant=abi.VARIANT_POOL, mode=abi.MODE_FAST, jitter=jit)
+    frames = {}
+    for det in (1, 0):
+        t = T.Tracer(0)
+        try:
+            t.set_tuning(deterministic=det)
+            t.scene_upload(pool_model.scene_view())
+            t.set_camera(g["trans"], g["width"], g["height"])
+            t.set_decay_origin((0, 0, 0, 1))
+            infos = []
+            for i in range(12):
+                img = t.render(**kw)
+                infos.append(t.last_render_info())
+            frames[det] = img
+            if det:
+                assert all(i["trialState"] == 0 and i["phasedTrips"] == 0 and i["handoverTrips"] == infos[0]["handoverTrips"] for i in infos), infos
+                assert infos[0]["handoverTrips"][:4] == [48, 48, 32, 16]
+                t.water_init(gx, gy, k, dt, w0, 0, tris[:nw])
+                t.water_step(100)
+                for i in range(12):                                  # (adaptive mode fits the tree again after a few of these: test_a_moved_scene_is_fitted_again_when_it_pays)
+                    t.render(**kw)
+                    assert t.scene_info()["ownBoxes"] == 0
+            else:
+                assert any(i["trialState"] != 0 for i in infos)
+        finally:
+            t.close()
+    assert np.array_equal(frames[0][0].view(np.uint32), frames[1][0].view(np.uint32)) and np.array_equal(frames[0][1], frames[1][1])
