@@ -574,7 +574,7 @@ __global__ void layoutRootKernel(uint32_t* stamp, uint32_t* pos, uint32_t* gs, u
 // assign: triangle leaves get their positions here (posOfTri written); else they are looked up (a second tree over the same triangles)
 __global__ __launch_bounds__(256) void layoutLevelKernel(const uint4* __restrict__ in, uint32_t nRecs, const uint32_t* __restrict__ sizeN, const uint32_t* __restrict__ sizeT,
                                                          uint32_t* stamp, uint32_t* pos, uint32_t* gs, uint32_t* ts, uint32_t level, uint4* __restrict__ out,
-                                                         uint32_t* posOfTri, uint32_t triCount, int assign) {
+                                                         uint32_t* posOfTri, uint32_t triCount, int assign, const uint4* __restrict__ auxIn, uint4* __restrict__ auxOut) {
     for (uint32_t r = blockIdx.x * 256u + threadIdx.x; r < nRecs; r += gridDim.x * 256u) {
         if (stamp[r] != level) continue;
         const uint4 q0 = in[size_t(r) * 4], q1 = in[size_t(r) * 4 + 1];
@@ -606,7 +606,284 @@ __global__ __launch_bounds__(256) void layoutLevelKernel(const uint4* __restrict
         q2.z = refs[0]; q2.w = refs[1]; q3.x = refs[2]; q3.y = refs[3];
         uint4* o = out + size_t(pos[r]) * 4;
         o[0] = q0; o[1] = q1; o[2] = q2; o[3] = q3;
+        if (auxIn) auxOut[pos[r]] = auxIn[r];          // what travels with a node (a caller's tree: where each item's box comes from, for the refit)
     }
+}
+
+// ---- a caller's tree (LrlSceneView.bvh: the reference's pre-order array of 64-B nodes, each with its own box, a primitive parked in any
+// node; /root/reference/RayTracing/RayTracing.h: BVH::Node) -> the two device layouts, on the device ----
+// What the host did until round 3 (validation stays there: it guards these kernels' indexing):
+//   1. callerScanKernel: which nodes are inner (-> record numbers by a prefix sum: recOf; binOf the other way); who would gain from a box of
+//      its own; whether the tree is nested (every child's box inside its parent's)
+//   2. callerDecideKernel: the fit applies when the tree is nested and at least 1 triangle in 64 gains
+//   3. callerLevelKernel, one launch per level of readiness, bottom-up: a record whose inner children were done by an EARLIER launch gets its
+//      fitted box, its binary record (caller's boxes: the PARITY kernels walk the tree as the reference does), its four-wide node as if it
+//      were the root of a collapse, where each item's box comes from (src4, for the refit below), and its four-wide subtree's sizes and height
+// The fit: the reference tests a primitive parked in an inner node whenever the ray enters that node's box, which spans a whole subtree, and
+// the Pool's tree has leaf boxes as tall as the highest wave (/root/reference/Pool/Pool.cpp:250-263).  A box fitted to the primitive says the
+// same for every ray that can hit it and turns most of the others away: a triangle's own box (primMin / primMax, kept current by the update
+// calls and the water step) with a margin `pad` on every side, where it lies inside the box the caller's tree gives that primitive; the
+// caller's box otherwise (other primitive classes: they go through the kernels' cold path, cheapest when the lanes of a wave take it together,
+// on arrival at the node; a triangle that has left its box: the caller's boxes are the contract, as for the reference); an inner node: the
+// union of its items.  Only for a nested tree: then a ray that hits a primitive reaches it through either set of boxes.  The margin: a hit on
+// the box's face (every hit on a triangle that lies in an axis plane, every hit on an edge that two neighbours' boxes share) must enter the box
+// safely before the hit's distance, or one of two primitives at exactly the same distance would be turned away by the rounding of the slab
+// arithmetic instead of being decided by its code (tests/test_gpu_parity.py::test_hand_over_kernels_agree).
+struct CNode { float3 lo, hi; uint32_t left, right, axis, geometry, num; };
+DI CNode ldNode(const LrlBVHNode* __restrict__ bvh, uint32_t b) {
+    const uint4* q = reinterpret_cast<const uint4*>(bvh + b);
+    const uint4 a = q[0], c = q[1], d = q[2];
+    return {make_float3(__uint_as_float(a.x), __uint_as_float(a.y), __uint_as_float(a.z)), make_float3(__uint_as_float(c.x), __uint_as_float(c.y), __uint_as_float(c.z)),
+            a.w, c.w, d.y, d.z, d.w};
+}
+DI uint32_t primBits(const CNode& n) { return (n.geometry << LRL_PRIM_TYPE_SHIFT) | (n.num & LRL_PRIM_INDEX_MASK); }
+struct OwnBoxes { const float4* pmin; const float4* pmax; uint32_t triCount; float pad; };
+// box of node n's primitive -> 0: the caller's; 1: its own, which is the caller's plus the margin; 2: its own, tighter
+DI int primBox(const OwnBoxes& o, const CNode& n, float3& lo, float3& hi) {
+    lo = n.lo; hi = n.hi;
+    if (!o.pmin || n.geometry != 2u || n.num >= o.triCount) return 0;
+    const float4 a = o.pmin[n.num], b = o.pmax[n.num];
+    const bool inside = a.x <= b.x && a.y <= b.y && a.z <= b.z && a.x >= lo.x && a.y >= lo.y && a.z >= lo.z && b.x <= hi.x && b.y <= hi.y && b.z <= hi.z;
+    if (!inside) return 0;
+    const bool same = a.x == lo.x && a.y == lo.y && a.z == lo.z && b.x == hi.x && b.y == hi.y && b.z == hi.z;
+    lo = make_float3(a.x - o.pad, a.y - o.pad, a.z - o.pad); hi = make_float3(b.x + o.pad, b.y + o.pad, b.z + o.pad);
+    return same ? 1 : 2;
+}
+DI bool within(const CNode& c, const CNode& p) {
+    return c.lo.x <= c.hi.x && c.lo.y <= c.hi.y && c.lo.z <= c.hi.z && c.lo.x >= p.lo.x && c.lo.y >= p.lo.y && c.lo.z >= p.lo.z && c.hi.x <= p.hi.x && c.hi.y <= p.hi.y && c.hi.z <= p.hi.z;
+}
+// info words of the caller's-tree kernels
+enum { CT_HEIGHT4 = 0, CT_GAINERS = 1, CT_NOT_NESTED = 2, CT_SIZE_N = 3, CT_SIZE_T = 4, CT_FITTED = 5, CT_ROOT_DONE = 6, CT_FIT = 7 };
+__global__ __launch_bounds__(256) void callerScanKernel(const LrlBVHNode* __restrict__ bvh, uint32_t N, OwnBoxes own, uint32_t* __restrict__ flags, uint32_t* info) {
+    const uint32_t i = blockIdx.x * 256u + threadIdx.x;
+    bool gain = false, loose = false;
+    if (i < N) {
+        const CNode n = ldNode(bvh, i);
+        flags[i] = n.left ? 1u : 0u;
+        if (own.pmin) {
+            if (n.geometry) { float3 lo, hi; const int k = primBox(own, n, lo, hi); gain = n.left ? k != 0 : k == 2; }
+            if (n.left) {
+                loose = !within(ldNode(bvh, i + 1u), n);
+                if (n.right) loose = loose || !within(ldNode(bvh, n.right), n);
+            }
+        }
+    }
+    const uint32_t gainers = uint32_t(__popcll(__ballot(gain)));
+    const bool anyLoose = __ballot(loose) != 0ull;
+    if ((threadIdx.x & 63u) == 0u) {
+        if (gainers) atomicAdd(&info[CT_GAINERS], gainers);
+        if (anyLoose) atomicOr(&info[CT_NOT_NESTED], 1u);
+    }
+}
+__global__ __launch_bounds__(256) void callerBinOfKernel(const uint32_t* __restrict__ flags, const uint32_t* __restrict__ recOf, uint32_t N, uint32_t* __restrict__ binOf) {
+    const uint32_t i = blockIdx.x * 256u + threadIdx.x;
+    if (i < N && flags[i]) binOf[recOf[i]] = i;
+}
+__global__ void callerDecideKernel(uint32_t* info, uint32_t triCount, int haveOwn) {
+    if (threadIdx.x == 0 && blockIdx.x == 0)
+        info[CT_FIT] = (haveOwn && info[CT_NOT_NESTED] == 0u && info[CT_GAINERS] != 0u && uint64_t(info[CT_GAINERS]) * 64u >= triCount) ? 1u : 0u;
+}
+struct CItem { float3 lo, hi; uint32_t ref, src; };      // ref: record index or LRL_REF_LEAF | primitive; src: binary node (bit 31: the primitive parked in it)
+struct CallerTree {
+    const LrlBVHNode* bvh; const uint32_t* recOf; const float4* nodeMin; const float4* nodeMax; OwnBoxes own;
+};
+DI void childItem(const CallerTree& t, uint32_t c, CItem* out, int& k, uint32_t* fitted) {
+    const CNode n = ldNode(t.bvh, c);
+    if (n.left) {
+        const uint32_t r = t.recOf[c];
+        const float4 a = t.nodeMin[r], b = t.nodeMax[r];
+        out[k++] = {make_float3(a.x, a.y, a.z), make_float3(b.x, b.y, b.z), r, c};
+    } else if (n.geometry) {
+        float3 lo, hi;
+        const int own = primBox(t.own, n, lo, hi);
+        if (fitted && own == 2) ++*fitted;
+        out[k++] = {lo, hi, LRL_REF_LEAF | primBits(n), c};
+    }
+}
+// the items of binary node b: its parked primitive, its children (a leaf without a primitive is none)
+DI int contents(const CallerTree& t, uint32_t b, const CNode& n, CItem* out, uint32_t* fitted) {
+    int k = 0;
+    if (n.geometry) {
+        float3 lo, hi;
+        const int own = primBox(t.own, n, lo, hi);
+        if (fitted && own != 0) ++*fitted;
+        out[k++] = {lo, hi, LRL_REF_LEAF | primBits(n), b | 0x80000000u};
+    }
+    if (n.left) {
+        childItem(t, b + 1u, out, k, fitted);
+        if (n.right) childItem(t, n.right, out, k, fitted);
+    }
+    return k;
+}
+DI float area(const CItem& t) {
+    const float dx = t.hi.x - t.lo.x, dy = t.hi.y - t.lo.y, dz = t.hi.z - t.lo.z;
+    return dx * dy + dy * dz + dz * dx;
+}
+DI void writeCallerNode4(const CItem* it, int n, uint32_t r, uint4* node4, uint4* src4) {
+    if (n) {
+        Item4 q[4];
+        for (int i = 0; i < n; ++i) q[i] = {it[i].lo, it[i].hi, it[i].ref};
+        writeNode4(q, n, r, node4);
+    } else {      // nothing below: four empty slots (inverted boxes)
+        uint4* q = node4 + size_t(r) * 4;
+        q[0] = make_uint4(0u, 0u, 0u, 127u << 23);
+        q[1] = make_uint4(0xffffffffu, 0xffffffffu, 0xffffffffu, 0u);
+        q[2] = make_uint4(0u, 0u, LRL_REF_EMPTY4, LRL_REF_EMPTY4);
+        q[3] = make_uint4(LRL_REF_EMPTY4, LRL_REF_EMPTY4, 127u << 23, 127u << 23);
+    }
+    src4[r] = make_uint4(n > 0 ? it[0].src : 0u, n > 1 ? it[1].src : 0u, n > 2 ? it[2].src : 0u, n > 3 ? it[3].src : 0u);
+}
+DI uint32_t leafRefOf(const CNode& n) { return LRL_REF_LEAF | (n.geometry << LRL_PRIM_TYPE_SHIFT) | (n.num & LRL_PRIM_INDEX_MASK); }
+// records 1 .. recCount-1 (record r replaces binary node binOf[r]); the thread that does the root's also writes record 0, the root's virtual parent
+__global__ __launch_bounds__(256) void callerLevelKernel(const LrlBVHNode* __restrict__ bvh, const uint32_t* __restrict__ recOf, const uint32_t* __restrict__ binOf, uint32_t recCount,
+                                                         OwnBoxes own, uint32_t* doneAt, uint32_t launch, float4* nodeMin, float4* nodeMax, float4* recs, uint4* node4,
+                                                         uint4* src4, uint32_t* h4, uint32_t* sizeN, uint32_t* sizeT, uint32_t* info) {
+    const bool fit = info[CT_FIT] != 0u;
+    if (!fit) own.pmin = nullptr;
+    const CallerTree t{bvh, recOf, nodeMin, nodeMax, own};
+    uint32_t fitted = 0;
+    for (uint32_t r = 1u + blockIdx.x * 256u + threadIdx.x; r < recCount; r += gridDim.x * 256u) {
+        if (doneAt[r] != 0u) continue;
+        const uint32_t b = binOf[r];
+        const CNode n = ldNode(bvh, b);
+        const CNode l = ldNode(bvh, b + 1u);
+        CNode rt = l;
+        if (n.right) rt = ldNode(bvh, n.right);
+        bool ready = true;
+        if (l.left) { const uint32_t d = doneAt[recOf[b + 1u]]; ready = ready && d != 0u && d < launch; }
+        if (n.right && rt.left) { const uint32_t d = doneAt[recOf[n.right]]; ready = ready && d != 0u && d < launch; }
+        if (!ready) continue;
+        // the binary record: both children's boxes as the caller has them
+        {
+            float4* q = recs + size_t(r) * 4;
+            const uint32_t ownPrim = n.geometry ? primBits(n) : 0u;
+            const uint32_t lref = l.left ? recOf[b + 1u] : leafRefOf(l);
+            q[0] = make_float4(l.lo.x, l.lo.y, l.lo.z, __uint_as_float(lref));
+            if (n.right) {
+                const uint32_t rref = rt.left ? recOf[n.right] : leafRefOf(rt);
+                q[1] = make_float4(l.hi.x, l.hi.y, l.hi.z, __uint_as_float(rref));
+                q[2] = make_float4(rt.lo.x, rt.lo.y, rt.lo.z, __uint_as_float(ownPrim));
+                q[3] = make_float4(rt.hi.x, rt.hi.y, rt.hi.z, __uint_as_float(n.axis));
+            } else {
+                q[1] = make_float4(l.hi.x, l.hi.y, l.hi.z, __uint_as_float(LRL_REF_NONE));
+                q[2] = make_float4(0.0f, 0.0f, 0.0f, __uint_as_float(ownPrim));
+                q[3] = make_float4(0.0f, 0.0f, 0.0f, __uint_as_float(n.axis));
+            }
+        }
+        CItem it[8];
+        int cnt = contents(t, b, n, it, &fitted);
+        // this node's box: fitted = the union of its items; else the caller's
+        float3 lo = n.lo, hi = n.hi;
+        if (fit && cnt) {
+            lo = it[0].lo; hi = it[0].hi;
+            for (int i = 1; i < cnt; ++i) {
+                lo = make_float3(fminf(lo.x, it[i].lo.x), fminf(lo.y, it[i].lo.y), fminf(lo.z, it[i].lo.z));
+                hi = make_float3(fmaxf(hi.x, it[i].hi.x), fmaxf(hi.y, it[i].hi.y), fmaxf(hi.z, it[i].hi.z));
+            }
+        }
+        nodeMin[r] = make_float4(lo.x, lo.y, lo.z, 0.0f); nodeMax[r] = make_float4(hi.x, hi.y, hi.z, 0.0f);
+        // the collapse: an inner item is replaced by ITS items while the node stays within four, largest box first
+        for (;;) {
+            int best = -1, bestAdd = 0;
+            float bestArea = -1.0f;
+            CItem sub[3], bestSub[3];
+            for (int i = 0; i < cnt; ++i) {
+                if (!inner(it[i].ref)) continue;
+                const float a = area(it[i]);
+                if (!(a > bestArea)) continue;
+                const int add = contents(t, it[i].src, ldNode(bvh, it[i].src), sub, nullptr);
+                if (cnt - 1 + add > 4) continue;
+                bestArea = a; best = i; bestAdd = add;
+                for (int k = 0; k < add; ++k) bestSub[k] = sub[k];
+            }
+            if (best < 0) break;
+            for (int i = best; i + 1 < cnt; ++i) it[i] = it[i + 1];
+            --cnt;
+            for (int k = 0; k < bestAdd; ++k) it[cnt++] = bestSub[k];
+        }
+        writeCallerNode4(it, cnt, r, node4, src4);
+        uint32_t hw = 0, sN = 1u, sT = 0u;
+        for (int i = 0; i < cnt; ++i)
+            if (inner(it[i].ref)) { hw = max(hw, h4[it[i].ref]); sN += sizeN[it[i].ref]; sT += sizeT[it[i].ref]; }
+            else if (triLeaf(it[i].ref)) ++sT;
+        h4[r] = hw + 1u; sizeN[r] = sN; sizeT[r] = sT;
+        if (b == 0u) {      // record 0: the root replaced by its items, then as above: the same node
+            recs[0] = make_float4(n.lo.x, n.lo.y, n.lo.z, __uint_as_float(r));
+            recs[1] = make_float4(n.hi.x, n.hi.y, n.hi.z, __uint_as_float(LRL_REF_NONE));
+            recs[2] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+            recs[3] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+            writeCallerNode4(it, cnt, 0u, node4, src4);
+            h4[0] = hw + 1u; sizeN[0] = sN; sizeT[0] = sT;
+            info[CT_HEIGHT4] = hw + 1u; info[CT_SIZE_N] = sN; info[CT_SIZE_T] = sT; info[CT_ROOT_DONE] = launch;
+        }
+        doneAt[r] = launch;
+    }
+    // (each primitive is counted once: by the launch that does the node it is an item of, before any collapse)
+    for (int o = 32; o; o >>= 1) fitted += __shfl_xor(fitted, o);
+    if ((threadIdx.x & 63u) == 0u && fitted) atomicAdd(&info[CT_FITTED], fitted);
+}
+// a tree whose root is a leaf: record 0 alone
+__global__ void callerLeafRootKernel(const LrlBVHNode* bvh, OwnBoxes own, float4* recs, uint4* node4, uint4* src4, uint32_t* h4, uint32_t* sizeN, uint32_t* sizeT, uint32_t* info) {
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    if (info[CT_FIT] == 0u) own.pmin = nullptr;
+    const CNode n = ldNode(bvh, 0u);
+    recs[0] = make_float4(n.lo.x, n.lo.y, n.lo.z, __uint_as_float(leafRefOf(n)));
+    recs[1] = make_float4(n.hi.x, n.hi.y, n.hi.z, __uint_as_float(LRL_REF_NONE));
+    recs[2] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+    recs[3] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+    CItem it[1];
+    int cnt = 0;
+    if (n.geometry) {
+        float3 lo, hi;
+        if (primBox(own, n, lo, hi) == 2) info[CT_FITTED] = 1u;
+        it[cnt++] = {lo, hi, LRL_REF_LEAF | primBits(n), 0u};
+    }
+    writeCallerNode4(it, cnt, 0u, node4, src4);
+    h4[0] = 1u; sizeN[0] = 1u; sizeT[0] = (cnt && triLeaf(it[0].ref)) ? 1u : 0u;
+    info[CT_HEIGHT4] = 1u; info[CT_SIZE_N] = 1u; info[CT_SIZE_T] = sizeT[0]; info[CT_ROOT_DONE] = 1u;
+}
+
+// ---- refit of a caller's four-wide tree to where its triangles are now ("a refit kernel for Pool's moving water instead
+// of tall static boxes", /root/reference/Pool/Pool.cpp:250-263) ----
+// The topology stays (refs, layout, depth); every node's child boxes are made again, bottom-up, by the rule above (primBox; an inner child:
+// the union of its own items).  src4 = per item the binary node of the caller's tree whose box that is (bit 31: the primitive parked in that node).
+// One launch per level of readiness, as fitLevelKernel: a node is done by the first launch that finds its inner children done earlier.
+__global__ __launch_bounds__(256) void refitLevelKernel(uint4* node4, uint32_t nodes, const uint4* __restrict__ src4, const LrlBVHNode* __restrict__ bvh,
+                                                        OwnBoxes own, float4* boxLo, float4* boxHi, uint32_t* doneAt, uint32_t launch, uint32_t* tight) {
+    uint32_t fitted = 0;
+    for (uint32_t r = blockIdx.x * 256u + threadIdx.x; r < nodes; r += gridDim.x * 256u) {
+        if (doneAt[r] != 0u) continue;
+        const uint4 q2 = node4[size_t(r) * 4 + 2], q3 = node4[size_t(r) * 4 + 3], s = src4[r];
+        const uint32_t refs[4] = {q2.z, q2.w, q3.x, q3.y}, srcs[4] = {s.x, s.y, s.z, s.w};
+        bool ready = true;
+        for (int i = 0; i < 4; ++i)
+            if (inner(refs[i])) {
+                const uint32_t d = refs[i] < nodes ? doneAt[refs[i]] : 1u;
+                ready = ready && d != 0u && d < launch;
+            }
+        if (!ready) continue;
+        Item4 it[4];
+        int n = 0;
+        float3 nlo = make_float3(INFINITY, INFINITY, INFINITY), nhi = make_float3(-INFINITY, -INFINITY, -INFINITY);
+        for (int i = 0; i < 4; ++i) {
+            const uint32_t ref = refs[i];
+            if (ref == LRL_REF_EMPTY4) continue;                  // (empty slots are the last ones)
+            float3 lo, hi;
+            if (inner(ref) && ref < nodes) { const float4 a = boxLo[ref], b = boxHi[ref]; lo = make_float3(a.x, a.y, a.z); hi = make_float3(b.x, b.y, b.z); }
+            else {
+                const int k = primBox(own, ldNode(bvh, srcs[i] & 0x7fffffffu), lo, hi);
+                fitted += ((srcs[i] >> 31) ? k != 0 : k == 2) ? 1u : 0u;
+            }
+            it[n++] = {lo, hi, ref};
+            nlo = make_float3(fminf(nlo.x, lo.x), fminf(nlo.y, lo.y), fminf(nlo.z, lo.z));
+            nhi = make_float3(fmaxf(nhi.x, hi.x), fmaxf(nhi.y, hi.y), fmaxf(nhi.z, hi.z));
+        }
+        if (n) writeNode4(it, n, r, node4);
+        boxLo[r] = make_float4(nlo.x, nlo.y, nlo.z, 0.0f); boxHi[r] = make_float4(nhi.x, nhi.y, nhi.z, 0.0f);
+        doneAt[r] = launch;
+    }
+    for (int o = 32; o; o >>= 1) fitted += __shfl_xor(fitted, o);
+    if ((threadIdx.x & 63u) == 0u && fitted) atomicAdd(tight, fitted);      // primitives bounded more tightly than by the caller's tree
 }
 // triLeaf[posOfTri[i]] = triHot[i], with the triangle's number in the record (the kernels report hits by it)
 __global__ __launch_bounds__(256) void triLeafGatherKernel(const float4* __restrict__ triHot, const uint32_t* __restrict__ posOfTri, uint32_t first, uint32_t count,
@@ -630,7 +907,7 @@ size_t lrl_layout_scratch_bytes(uint32_t nRecs) { return (size_t(nRecs) * 4 + 25
 // four-wide tree (or more); out: sizeN[0] nodes; posOfTri: triCount entries (assign: written, LRL_REF_NONE where the tree holds no such
 // triangle; else read).  scratch: lrl_layout_scratch_bytes(nRecs).
 hipError_t lrl_layout_node4(const uint4* in, uint32_t nRecs, const uint32_t* sizeN, const uint32_t* sizeT, uint32_t levels, void* scratch, uint4* out,
-                            uint32_t* posOfTri, uint32_t triCount, bool assign, hipStream_t stream) {
+                            uint32_t* posOfTri, uint32_t triCount, bool assign, const uint4* auxIn, uint4* auxOut, hipStream_t stream) {
     const size_t part = (size_t(nRecs) * 4 + 255) / 256 * 256;
     char* p = static_cast<char*>(scratch);
     uint32_t* stamp = reinterpret_cast<uint32_t*>(p);
@@ -643,7 +920,81 @@ hipError_t lrl_layout_node4(const uint4* in, uint32_t nRecs, const uint32_t* siz
     hipLaunchKernelGGL(lrl_build::layoutRootKernel, dim3(1), dim3(64), 0, stream, stamp, pos, gs, ts);
     const dim3 grid(std::min<uint32_t>((nRecs + 255u) / 256u, 16384u));
     for (uint32_t level = 1; level <= levels; ++level)
-        hipLaunchKernelGGL(lrl_build::layoutLevelKernel, grid, dim3(256), 0, stream, in, nRecs, sizeN, sizeT, stamp, pos, gs, ts, level, out, posOfTri, triCount, assign ? 1 : 0);
+        hipLaunchKernelGGL(lrl_build::layoutLevelKernel, grid, dim3(256), 0, stream, in, nRecs, sizeN, sizeT, stamp, pos, gs, ts, level, out, posOfTri, triCount, assign ? 1 : 0, auxIn, auxOut);
+    return hipGetLastError();
+}
+
+namespace {
+struct CallerScratch { uint32_t *flags, *recOf, *binOf, *doneAt, *h4, *sizeN, *sizeT; float4 *nodeMin, *nodeMax; void* scanBuf; size_t scanTmp; size_t bytes; };
+CallerScratch callerScratch(void* scratch, uint32_t N, uint32_t recCount) {
+    char* p = static_cast<char*>(scratch);
+    auto take = [&](size_t bytes) { char* o = p; p += (bytes + 255) / 256 * 256; return o; };
+    CallerScratch c{};
+    c.flags = reinterpret_cast<uint32_t*>(take(size_t(N) * 4));
+    c.recOf = reinterpret_cast<uint32_t*>(take(size_t(N) * 4));
+    c.binOf = reinterpret_cast<uint32_t*>(take(size_t(recCount) * 4));
+    c.doneAt = reinterpret_cast<uint32_t*>(take(size_t(recCount) * 4));
+    c.h4 = reinterpret_cast<uint32_t*>(take(size_t(recCount) * 4));
+    c.sizeN = reinterpret_cast<uint32_t*>(take(size_t(recCount) * 4));
+    c.sizeT = reinterpret_cast<uint32_t*>(take(size_t(recCount) * 4));
+    c.nodeMin = reinterpret_cast<float4*>(take(size_t(recCount) * 16));
+    c.nodeMax = reinterpret_cast<float4*>(take(size_t(recCount) * 16));
+    uint32_t* v = nullptr;
+    (void)rocprim::exclusive_scan(nullptr, c.scanTmp, v, v, 1u, size_t(N), rocprim::plus<uint32_t>(), hipStream_t(nullptr));
+    c.scanBuf = take(c.scanTmp);
+    c.bytes = size_t(p - static_cast<char*>(scratch));
+    return c;
+}
+}  // namespace
+size_t lrl_caller_tree_scratch_bytes(uint32_t N, uint32_t recCount) { return callerScratch(nullptr, N, recCount).bytes; }
+// bvh: the caller's N nodes (validated on the host, on the device here); recCount = 1 + its inner nodes; levels: the binary tree's height (or
+// more); pmin / pmax: the triangles' own boxes (NULL: none known, no fit).  Out: recs, node4 (by record index), src4: recCount entries each;
+// sizes[0..1]: the four-wide subtree sizes in `scratch`, for lrl_layout_node4; info (host-visible once the stream is synchronised):
+// {four-wide height, gainers, 1 if not nested, four-wide nodes, triangle leaves, primitives fitted more tightly, launch that did the root (0: not reached), 1 if fitted}
+hipError_t lrl_caller_tree(const LrlBVHNode* bvh, uint32_t N, uint32_t recCount, uint32_t levels, const float4* pmin, const float4* pmax, uint32_t triCount, float pad,
+                           void* scratch, float4* recs, uint4* node4, uint4* src4, const uint32_t** sizes, uint32_t* infoDev, hipStream_t stream) {
+    if (!N || !recCount) return hipErrorInvalidValue;
+    const CallerScratch c = callerScratch(scratch, N, recCount);
+    sizes[0] = c.sizeN; sizes[1] = c.sizeT;
+    hipError_t e;
+    if ((e = hipMemsetAsync(infoDev, 0, 32, stream)) != hipSuccess) return e;
+    if ((e = hipMemsetAsync(c.doneAt, 0, size_t(recCount) * 4, stream)) != hipSuccess) return e;
+    const lrl_build::OwnBoxes own{pmin, pmax, triCount, pad};
+    const dim3 blk(256), grd((N + 255u) / 256u);
+    hipLaunchKernelGGL(lrl_build::callerScanKernel, grd, blk, 0, stream, bvh, N, own, c.flags, infoDev);
+    size_t tmp = c.scanTmp;
+    if ((e = rocprim::exclusive_scan(c.scanBuf, tmp, c.flags, c.recOf, 1u, size_t(N), rocprim::plus<uint32_t>(), stream)) != hipSuccess) return e;
+    hipLaunchKernelGGL(lrl_build::callerBinOfKernel, grd, blk, 0, stream, c.flags, c.recOf, N, c.binOf);
+    hipLaunchKernelGGL(lrl_build::callerDecideKernel, dim3(1), dim3(64), 0, stream, infoDev, triCount, pmin ? 1 : 0);
+    if (recCount == 1u) {
+        hipLaunchKernelGGL(lrl_build::callerLeafRootKernel, dim3(1), dim3(64), 0, stream, bvh, own, recs, node4, src4, c.h4, c.sizeN, c.sizeT, infoDev);
+        return hipGetLastError();
+    }
+    const dim3 lgrd(std::min<uint32_t>((recCount + 255u) / 256u, 32768u));
+    for (uint32_t launch = 1; launch <= levels; ++launch)
+        hipLaunchKernelGGL(lrl_build::callerLevelKernel, lgrd, blk, 0, stream, bvh, c.recOf, c.binOf, recCount, own, c.doneAt, launch, c.nodeMin, c.nodeMax, recs, node4, src4,
+                           c.h4, c.sizeN, c.sizeT, infoDev);
+    return hipGetLastError();
+}
+
+size_t lrl_refit_scratch_bytes(uint32_t nodes) { return size_t(nodes) * (16 + 16 + 4) + 1024; }
+// (-> the word after the nodes' stamps: how many primitives the refitted tree bounds more tightly than the caller's does)
+const uint32_t* lrl_refit_tight_count(const void* scratch, uint32_t nodes) {
+    return reinterpret_cast<const uint32_t*>(static_cast<const char*>(scratch) + size_t(nodes) * 32) + nodes;
+}
+// node4: `nodes` four-wide nodes (laid out or by record index) of a caller's tree `bvh`; src4: per node, the binary node behind each of its
+// items (bit 31: its parked primitive); pmin / pmax: the triangles' own boxes as they are now; levels: height of the four-wide tree (or more)
+hipError_t lrl_refit_node4(uint4* node4, uint32_t nodes, const uint4* src4, const LrlBVHNode* bvh, const float4* pmin, const float4* pmax, uint32_t triCount,
+                           float pad, uint32_t levels, void* scratch, hipStream_t stream) {
+    char* p = static_cast<char*>(scratch);
+    float4* boxLo = reinterpret_cast<float4*>(p);
+    float4* boxHi = boxLo + nodes;
+    uint32_t* doneAt = reinterpret_cast<uint32_t*>(boxHi + nodes);
+    hipError_t e = hipMemsetAsync(doneAt, 0, size_t(nodes) * 4 + 4, stream);      // (and the count behind them)
+    if (e != hipSuccess) return e;
+    const dim3 grid(std::min<uint32_t>((nodes + 255u) / 256u, 16384u));
+    for (uint32_t launch = 1; launch <= levels; ++launch)
+        hipLaunchKernelGGL(lrl_build::refitLevelKernel, grid, dim3(256), 0, stream, node4, nodes, src4, bvh, lrl_build::OwnBoxes{pmin, pmax, triCount, pad}, boxLo, boxHi, doneAt, launch, doneAt + nodes);
     return hipGetLastError();
 }
 

@@ -54,10 +54,17 @@ struct LrlContext {
     DevBuf waterPoints, waterTris, waterMat;   // Pool water simulation (lrl_water_*)
     uint32_t waterGX = 0, waterGY = 0, waterFirst = 0;
     float waterK = 0, waterDt = 0;
-    DevBuf nodes, nodes32, nodes32Loose, triHot, triCold, materials, spheres, circles, cylinders, cones, lights, tex, cube, triStage, matStage;
-    // the four-wide tree as the rays walk it (lrl_layout_node4): nodes32 / nodes32Loose hold the laid-out nodes, triLeaf the hot records in the
+    DevBuf nodes, nodes32, triHot, triCold, materials, spheres, circles, cylinders, cones, lights, tex, cube, triStage, matStage;
+    // the four-wide tree as the rays walk it (lrl_layout_node4): nodes32 holds the laid-out nodes, triLeaf the hot records in the
     // order of their leaves, posOfTri where each triangle's record went
-    DevBuf nodes32Raw, layoutScratch, layoutSizes, triLeaf, posOfTri;
+    DevBuf nodes32Raw, layoutScratch, triLeaf, posOfTri;
+    // a caller's tree on the device (lrl_caller_tree): its nodes and where each four-wide item's box comes from are kept while the tree is
+    // fitted to the triangles' own boxes (fitActive), for the refit that follows them (lrl_refit_node4)
+    DevBuf bvhDev, src4, src4Raw, callerScratch, refitScratch;
+    bool fitActive = false;
+    bool refitted = false;        // the count of tightly bounded primitives is the last refit's (in refitScratch), not the upload's
+    bool triBoxes = false;        // primMin / primMax hold every triangle's box as it is now
+    float fitPad = 0.0f;
     bool leafOrder = false;        // triLeaf / posOfTri are in use (else the four-wide kernels read triHot itself)
     uint32_t wideNodes = 0;        // four-wide nodes in use (nodes32)
     uint32_t texW = 0, texH = 0, texL = 0, cubeSize = 0;
@@ -65,12 +72,7 @@ struct LrlContext {
     std::unordered_map<ColorKey, uint32_t, ColorHash> materialIndex;
     // callers' trees: the triangles' own boxes (six floats each, min > max: not known), kept current by the update calls; the
     // four-wide tree is fitted to them (fitOwnBoxes)
-    std::vector<float> ownBox;
-    uint32_t parkedTight = 0;     // triangles that nodes32 bounds by their own boxes (fitOwnBoxes)
-    bool haveLoose = false;       // nodes32Loose holds the same four-wide tree with the caller's boxes only
-    bool looseInUse = false;      // primitives changed under the caller's tree since it came: its boxes alone are the contract (ownBoxesStale)
-    std::vector<LrlBVHNode> callerTree;   // the caller's tree, kept where fitting pays: a scene that has come to rest is fitted again (refitAtRest)
-    uint64_t pathsAtRest = 0;     // paths (pixels x samples) rendered since the last change under the caller's tree
+    uint32_t parkedTight = 0;     // primitives that nodes32 bounds more tightly than the caller's tree does (lrl_caller_tree)
 
     // frame
     LrlTrans trans{};
@@ -143,6 +145,5 @@ void fillKScene(const LrlContext* c, KScene& k);
 LrlTuning defaultTuning();
 // lrl_scene.hip
 hipError_t noallocScratchFor(int device, void** out);      // this device's copy of the static staging array of lrl_scene_update_triangles_noalloc
-int refitAtRest(LrlContext* c, uint64_t paths);            // a moved scene is fitted again when the rendering since the move is worth it
 
 }  // namespace lrl_host

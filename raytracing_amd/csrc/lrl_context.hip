@@ -35,7 +35,7 @@ int orderAfterRenders(LrlContext* c) {
 
 void fillKScene(const LrlContext* c, KScene& k) {
     k.recs = static_cast<const float4*>(c->nodes.p);
-    k.node4 = static_cast<const uint4*>(c->looseInUse ? c->nodes32Loose.p : c->nodes32.p);
+    k.node4 = static_cast<const uint4*>(c->nodes32.p);
     k.triHot = static_cast<const float4*>(c->triHot.p);
     k.triLeaf = static_cast<const float4*>(c->leafOrder ? c->triLeaf.p : c->triHot.p);
     k.triCold = static_cast<const LrlTriCold*>(c->triCold.p);
@@ -159,7 +159,7 @@ int lrl_destroy(LrlContext* c) {
     // writes its feedback into the pinned words
     if (c->renderedOnce && c->evLastRender) (void)hipEventSynchronize(c->evLastRender);
     if (c->evCont) (void)hipEventSynchronize(c->evCont);
-    for (DevBuf* b : {&c->nodes32Raw, &c->layoutScratch, &c->layoutSizes, &c->triLeaf, &c->posOfTri, &c->primMin, &c->primMax, &c->buildScratch, &c->buildInfo, &c->waterPoints, &c->waterTris, &c->waterMat, &c->nodes, &c->nodes32, &c->nodes32Loose, &c->triHot, &c->triCold, &c->materials, &c->spheres, &c->circles, &c->cylinders, &c->cones, &c->lights,
+    for (DevBuf* b : {&c->nodes32Raw, &c->layoutScratch, &c->bvhDev, &c->src4, &c->src4Raw, &c->callerScratch, &c->refitScratch, &c->triLeaf, &c->posOfTri, &c->primMin, &c->primMax, &c->buildScratch, &c->buildInfo, &c->waterPoints, &c->waterTris, &c->waterMat, &c->nodes, &c->nodes32, &c->triHot, &c->triCold, &c->materials, &c->spheres, &c->circles, &c->cylinders, &c->cones, &c->lights,
                       &c->tex, &c->cube, &c->triStage, &c->matStage, &c->transDev, &c->outDev, &c->hitDev, &c->counterDev, &c->decayDev, &c->timelineDev, &c->wfArena})
         release(*b);
     for (auto& e : c->timingEvents) { (void)hipEventDestroy(e.first); (void)hipEventDestroy(e.second); }
@@ -279,7 +279,13 @@ int lrl_scene_info(const LrlContext* c, LrlSceneInfo* out) {
     if (!c->haveScene) return LRL_ERR_NO_SCENE;
     out->bvhNodes = c->nodeNum; out->bvhRecords = c->recNum; out->bvhDepth = c->bvhDepth; out->wideDepth = c->node4Depth;
     out->deviceBuilt = c->deviceBuilt ? 1u : 0u; out->materials = uint32_t(c->materialTable.size());
-    out->ownBoxes = c->looseInUse ? 0u : c->parkedTight;
+    out->ownBoxes = c->parkedTight;
+    if (c->fitActive && c->refitted) {      // the tree has followed its triangles since it came: the last refit's count (this call waits for it)
+        uint32_t tight = 0;
+        if (hipSetDevice(c->device) != hipSuccess || hipStreamSynchronize(c->stream) != hipSuccess ||
+            hipMemcpy(&tight, lrl_refit_tight_count(c->refitScratch.p, c->wideNodes), 4, hipMemcpyDeviceToHost) != hipSuccess) return LRL_ERR_DEVICE;
+        out->ownBoxes = tight;
+    }
     out->wideNodes = c->wideNodes; out->leafOrder = c->leafOrder ? 1u : 0u;
     return LRL_OK;
 }
@@ -292,7 +298,7 @@ int lrl_last_render_info(const LrlContext* c, LrlRenderInfo* out) {
 
 int lrl_scene_device_bytes(LrlContext* c, uint64_t out[4]) {
     if (!c || !out) return LRL_ERR_INVALID_ARG;
-    out[0] = uint64_t(c->recNum) * 64 + uint64_t(c->wideNodes) * 64 * (c->haveLoose ? 2 : 1);      // binary records + the four-wide nodes in use (two copies where a caller's tree is fitted)
+    out[0] = uint64_t(c->recNum) * 64 + uint64_t(c->wideNodes) * 64;      // binary records + the four-wide nodes in use
     out[1] = uint64_t(c->num.triangleNum) * 64 * (c->leafOrder ? 2 : 1);      // hot records by triangle number (+ the copy in leaf order)
     out[2] = uint64_t(c->num.triangleNum) * sizeof(LrlTriCold) + c->materialTable.size() * sizeof(LrlColor);
     out[3] = uint64_t(c->num.sphereNum + c->num.circleNum + c->num.cylinderNum + c->num.coneNum) * 128 + uint64_t(c->num.pointLightNum) * 32 +

@@ -227,7 +227,17 @@ hipError_t lrl_build_bvh(const float4* pmin, const float4* pmax, uint32_t n, flo
 // subtree, and the matching order of the triangles' hot records (triLeaf[posOfTri[i]] = triHot[i] with i inside the record).
 size_t lrl_layout_scratch_bytes(uint32_t nRecs);
 hipError_t lrl_layout_node4(const uint4* in, uint32_t nRecs, const uint32_t* sizeN, const uint32_t* sizeT, uint32_t levels, void* scratch, uint4* out,
-                            uint32_t* posOfTri, uint32_t triCount, bool assign, hipStream_t stream);
+                            uint32_t* posOfTri, uint32_t triCount, bool assign, const uint4* auxIn, uint4* auxOut, hipStream_t stream);
+// A caller's tree (validated) -> binary records, four-wide nodes by record index, their items' sources (src4), subtree sizes; the fit to the
+// triangles' own boxes where it applies (lrl_build.hip)
+size_t lrl_caller_tree_scratch_bytes(uint32_t N, uint32_t recCount);
+hipError_t lrl_caller_tree(const LrlBVHNode* bvh, uint32_t N, uint32_t recCount, uint32_t levels, const float4* pmin, const float4* pmax, uint32_t triCount, float pad,
+                           void* scratch, float4* recs, uint4* node4, uint4* src4, const uint32_t** sizes, uint32_t* infoDev, hipStream_t stream);
+// Refit of a caller's four-wide tree to the triangles' current boxes, in place, on the device (lrl_build.hip)
+size_t lrl_refit_scratch_bytes(uint32_t nodes);
+const uint32_t* lrl_refit_tight_count(const void* scratch, uint32_t nodes);
+hipError_t lrl_refit_node4(uint4* node4, uint32_t nodes, const uint4* src4, const LrlBVHNode* bvh, const float4* pmin, const float4* pmax, uint32_t triCount,
+                           float pad, uint32_t levels, void* scratch, hipStream_t stream);
 hipError_t lrl_launch_tri_leaf_gather(const float4* triHot, const uint32_t* posOfTri, uint32_t first, uint32_t count, float4* triLeaf, hipStream_t stream);
 hipError_t lrl_launch_quantize(const float4* in, uchar4* out, unsigned long long pixels, hipStream_t stream);   // RGBA32F -> RGBA8 (unorm)
 // Pool water simulation: `substeps` x (acceleration, position) on gx * gy points {z, v, a, blank} (<= 16384), then the

@@ -28,12 +28,14 @@ uint32_t internMaterial(LrlContext* c, const LrlColor& col) {
 }
 
 // Structural checks of the caller's BVH so that no lane can index outside a buffer or overrun its stack.
-int validateBVH(LrlContext* c, const LrlSceneView* s, uint32_t& depthOut) {
+int validateBVH(LrlContext* c, const LrlSceneView* s, uint32_t& depthOut, uint32_t& recCountOut) {
     const uint32_t N = s->bvhNodeNum;
     if (N == 0 || N >= LRL_REF_LEAF) return fail(c, LRL_ERR_INVALID_ARG, "bvhNodeNum out of range");
     const uint32_t counts[7] = {0, 0, s->num.triangleNum, s->num.sphereNum, s->num.circleNum, s->num.cylinderNum, s->num.coneNum};
+    uint32_t inner = 0;
     for (uint32_t i = 0; i < N; ++i) {
         const LrlBVHNode& n = s->bvh[i];
+        inner += n.bound.leftChild != 0 ? 1u : 0u;
         if (n.bound.leftChild != 0 && i + 1 >= N) return fail(c, LRL_ERR_INVALID_ARG, "BVH: left child past the end");
         if (n.bound.rightChild != 0 && (n.bound.rightChild < 0 || uint32_t(n.bound.rightChild) >= N || uint32_t(n.bound.rightChild) <= i))
             return fail(c, LRL_ERR_INVALID_ARG, "BVH: right child index invalid (must be a later pre-order index)");
@@ -60,6 +62,7 @@ int validateBVH(LrlContext* c, const LrlSceneView* s, uint32_t& depthOut) {
         if (n.bound.leftChild) st.emplace_back(i + 1, d + 1);
     }
     depthOut = depth;
+    recCountOut = 1u + inner;      // record 0 is the root's virtual parent
     if (depth + 1 > LRL_MAX_BVH_DEPTH) return fail(c, LRL_ERR_BVH_DEPTH, "BVH deeper than LRL_MAX_BVH_DEPTH");
     return LRL_OK;
 }
@@ -70,219 +73,7 @@ std::vector<uchar4> bgrToRgbx(const uint8_t* bgr, size_t texels) {
     return o;
 }
 
-// The caller's tree refitted to the primitives' own boxes, for the four-wide tree (buildNode4).
-// The reference tests a primitive parked in an inner node whenever the ray enters that node's box, which spans a whole subtree, and the
-// Pool's tree has leaf boxes as tall as the highest wave (Pool/Pool.cpp:250-263).  While the primitives are where they were when the tree
-// came, a box fitted to the primitive says the same for every ray that can hit it and turns most of the others away:
-//   park[b] = the parked primitive's own box                      (its node's box where the own box is not known or pokes out of it)
-//   node[b] = leaf: the primitive's own box (same rule); inner: union of park[b] and the children's node[] boxes
-// Only for a nested tree (every child's box inside its parent's) and own boxes inside the caller's: then a ray that hits a primitive reaches
-// it through either set of boxes, and the fitted ones (nested as well, a margin wider than the own boxes) only turn away rays that cannot hit.  `count`: primitives bounded more tightly than by the caller's tree.
-struct FittedBoxes { std::vector<float> node, park; size_t count = 0; };
-bool fitOwnBoxes(const LrlSceneView* s, const std::vector<float>& ownBox, FittedBoxes& f) {
-    const LrlBVHNode* bvh = s->bvh;
-    const uint32_t N = s->bvhNodeNum;
-    f = FittedBoxes();
-    if (ownBox.empty()) return false;
-    auto callers = [&](uint32_t b, float* q) { for (int a = 0; a < 3; ++a) { q[a] = bvh[b].bound.min[a]; q[3 + a] = bvh[b].bound.max[a]; } };
-    float scale = 0.0f;       // of the coordinates the slab arithmetic works with
-    for (int a = 0; a < 3 && N; ++a) scale = std::max(scale, std::max(std::fabs(bvh[0].bound.min[a]), std::fabs(bvh[0].bound.max[a])));
-    const float pad = std::ldexp(scale, -14);
-    auto inside = [](const float* q, const float* outer) {
-        for (int a = 0; a < 3; ++a) if (!(q[a] <= q[3 + a]) || q[a] < outer[a] || q[3 + a] > outer[3 + a]) return false;
-        return true;
-    };
-    // own box of node b's primitive into q if it is known and lies in the caller's box; else the caller's box.  -> strictly tighter
-    auto own = [&](uint32_t b, float* q, bool parked) {
-        const LrlBVHNode& n = bvh[b];
-        float outer[6];
-        callers(b, outer);
-        std::memcpy(q, outer, sizeof(outer));
-        // triangles only: the other kinds go through the kernels' cold path, which is cheapest when the lanes of a wave take it together,
-        // on arrival at the node (C1, where every kind is parked near the root: 1.53 ms of trace kernels as the caller's tree has them,
-        // 1.63 ms with own boxes for all kinds)
-        if (n.geometry != 2) return false;
-        const std::vector<float>& o = ownBox;
-        const size_t at = size_t(n.geometryNum) * 6;
-        if (at + 6 > o.size() || !inside(&o[at], outer)) return false;
-        // with a margin on every side: a hit on the box's face (every hit on a triangle that lies in an axis plane, every hit on an edge
-        // that two neighbours' boxes share) must enter the box safely before the hit's distance, or one of two primitives at exactly
-        // the same distance would be turned away by the rounding of the slab arithmetic instead of being decided by its code
-        // (tests/test_gpu_parity.py::test_hand_over_kernels_agree, the Pool seen along its grid's diagonal)
-        for (int a = 0; a < 3; ++a) { q[a] = o[at + a] - pad; q[3 + a] = o[at + 3 + a] + pad; }
-        return parked || std::memcmp(&o[at], outer, sizeof(outer)) != 0;
-    };
-    // who gains, before anything is allocated (few gainers: not worth the second copy of the tree that ownBoxesStale falls back to; C2's
-    // tree parks 0.5 % of its triangles)
-    size_t gainers = 0;
-    for (uint32_t b = 0; b < N; ++b) {
-        float q[6];
-        if (bvh[b].geometry) gainers += own(b, q, bvh[b].bound.leftChild != 0) ? 1 : 0;
-    }
-    if (gainers == 0 || gainers * 64 < ownBox.size() / 6) return false;
-    f.node.assign(size_t(N) * 6, 0.0f);
-    f.park.assign(size_t(N) * 6, 0.0f);
-    for (uint32_t b = N; b-- > 0;) {      // pre-order: children come after their parent
-        const LrlBVHNode& n = bvh[b];
-        float* q = &f.node[size_t(b) * 6];
-        if (!n.bound.leftChild) {
-            if (n.geometry) f.count += own(b, q, false) ? 1 : 0;
-            else callers(b, q);
-            continue;
-        }
-        float outer[6];
-        callers(b, outer);
-        bool any = false;
-        auto join = [&](const float* c) {
-            for (int a = 0; a < 3; ++a) { q[a] = any ? std::min(q[a], c[a]) : c[a]; q[3 + a] = any ? std::max(q[3 + a], c[3 + a]) : c[3 + a]; }
-            any = true;
-        };
-        if (n.geometry) { f.count += own(b, &f.park[size_t(b) * 6], true) ? 1 : 0; join(&f.park[size_t(b) * 6]); }
-        const uint32_t kids[2] = {b + 1, uint32_t(n.bound.rightChild)};
-        for (int k = 0; k < (n.bound.rightChild ? 2 : 1); ++k) {
-            float cb[6];
-            callers(kids[k], cb);
-            if (!inside(cb, outer)) { f = FittedBoxes(); return false; }      // not nested: the caller's boxes as they are
-            join(&f.node[size_t(kids[k]) * 6]);
-        }
-    }
-    return true;
-}
-
-// Four-wide, compressed repack of the caller's binary tree for the FAST lean kernel (lrl_lean.inc).  A node's items are
-// its parked primitive and its children; an inner child is replaced by ITS items while the node stays within four (largest
-// box first).  Boxes: the caller's, or the fitted ones (fitOwnBoxes).  The node of binary inner node b is stored at b's record index
-// (recOf[b], the index `recs` uses), so refs mean
-// the same in both trees and a ray can change from one to the other at any ref; record indices of binary nodes that were
-// merged into their parent stay unused.  64 B per node:
-//   {origin.x, origin.y, origin.z, unit.x}                       origin = min corner of the items' boxes; unit = per-axis
-//                                                                length of one byte step, a power of two (as a float)
-//   {lo.x of items 0..3 (one byte each), lo.y, lo.z, hi.x}       box = origin + byte * unit, rounded outwards
-//   {hi.y, hi.z, ref0, ref1}  {ref2, ref3, unit.y, unit.z}       ref: record index, LRL_REF_LEAF | primitive, or LRL_REF_EMPTY4 with an
-//                                                                inverted box (lo 255, hi 0) for an empty slot
-std::vector<uint4> buildNode4(const LrlSceneView* s, const FittedBoxes* fitted, const std::vector<uint32_t>& recOf, uint32_t recCount, uint32_t& depthOut) {
-    const LrlBVHNode* bvh = s->bvh;
-    struct Item { bool inner; uint32_t ref; float lo[3], hi[3]; };      // inner: binary node index; else primitive bits
-    auto primOf = [&](const LrlBVHNode& n) { return (uint32_t(n.geometry) << LRL_PRIM_TYPE_SHIFT) | (n.geometryNum & LRL_PRIM_INDEX_MASK); };
-    auto boxed = [&](bool inner, uint32_t ref, uint32_t boxOf, bool parked) {
-        Item it{inner, ref, {0, 0, 0}, {0, 0, 0}};
-        if (fitted) {
-            const float* q = parked ? &fitted->park[size_t(boxOf) * 6] : &fitted->node[size_t(boxOf) * 6];
-            for (int a = 0; a < 3; ++a) { it.lo[a] = q[a]; it.hi[a] = q[3 + a]; }
-        } else
-            for (int a = 0; a < 3; ++a) { it.lo[a] = bvh[boxOf].bound.min[a]; it.hi[a] = bvh[boxOf].bound.max[a]; }
-        return it;
-    };
-    auto asItem = [&](uint32_t cnode, Item* out, int& k) {
-        if (bvh[cnode].bound.leftChild) out[k++] = boxed(true, cnode, cnode, false);
-        else if (bvh[cnode].geometry) out[k++] = boxed(false, primOf(bvh[cnode]), cnode, false);
-    };
-    auto contents = [&](uint32_t b, Item* out) -> int {
-        const LrlBVHNode& n = bvh[b];
-        int k = 0;
-        if (n.geometry) out[k++] = boxed(false, primOf(n), b, true);
-        if (n.bound.leftChild) {
-            asItem(b + 1, out, k);
-            if (n.bound.rightChild) asItem(uint32_t(n.bound.rightChild), out, k);
-        }
-        return k;
-    };
-    auto area = [&](uint32_t b) {
-        const Item q = boxed(true, b, b, false);
-        float dx = q.hi[0] - q.lo[0], dy = q.hi[1] - q.lo[1], dz = q.hi[2] - q.lo[2];
-        return dx * dy + dy * dz + dz * dx;
-    };
-    auto fb = [](float f) { uint32_t v; std::memcpy(&v, &f, 4); return v; };
-    std::vector<uint4> out(size_t(recCount) * 4, make_uint4(0, 0, LRL_REF_EMPTY4, LRL_REF_EMPTY4));
-    struct Work { uint32_t bin; bool virt; uint32_t depth; };
-    std::vector<Work> work;
-    work.push_back({0u, true, 0u});
-    uint32_t depth = 0;
-    while (!work.empty()) {
-        const Work w = work.back();
-        work.pop_back();
-        depth = std::max(depth, w.depth);
-        Item items[8];
-        int n = 0;
-        if (w.virt) asItem(0u, items, n);      // record 0: the virtual parent of the root
-        else n = contents(w.bin, items);
-        for (;;) {
-            int best = -1;
-            float bestArea = -1.0f;
-            Item sub[3];
-            for (int i = 0; i < n; ++i) {
-                if (!items[i].inner) continue;
-                const int add = contents(items[i].ref, sub);
-                if (n - 1 + add > 4) continue;
-                const float a = area(items[i].ref);
-                if (a > bestArea) { bestArea = a; best = i; }
-            }
-            if (best < 0) break;
-            const int add = contents(items[best].ref, sub);
-            for (int i = best; i + 1 < n; ++i) items[i] = items[i + 1];
-            --n;
-            for (int i = 0; i < add; ++i) items[n++] = sub[i];
-        }
-        uint4* q = &out[size_t(w.virt ? 0u : recOf[w.bin]) * 4];
-        double lo[3] = {1e300, 1e300, 1e300}, hi[3] = {-1e300, -1e300, -1e300};
-        for (int i = 0; i < n; ++i)
-            for (int a = 0; a < 3; ++a) {
-                lo[a] = std::min(lo[a], double(items[i].lo[a]));
-                hi[a] = std::max(hi[a], double(items[i].hi[a]));
-            }
-        float origin[3] = {0, 0, 0};
-        uint32_t expo[3] = {127, 127, 127};
-        double unit[3] = {1, 1, 1};
-        for (int a = 0; a < 3 && n; ++a) {
-            origin[a] = float(lo[a]);
-            if (double(origin[a]) > lo[a]) origin[a] = std::nextafter(origin[a], -INFINITY);
-            const double ext = hi[a] - double(origin[a]);
-            int e = ext > 0 ? int(std::ceil(std::log2(ext / 255.0))) : -126;
-            e = std::min(127, std::max(-126, e));
-            while (e < 127 && std::ceil(ext / std::ldexp(1.0, e)) > 255.0) ++e;
-            expo[a] = uint32_t(e + 127);
-            unit[a] = std::ldexp(1.0, e);
-        }
-        uint32_t bytes[6] = {0, 0, 0, 0, 0, 0};      // lo.x lo.y lo.z hi.x hi.y hi.z, item i in byte i
-        uint32_t refs[4] = {LRL_REF_EMPTY4, LRL_REF_EMPTY4, LRL_REF_EMPTY4, LRL_REF_EMPTY4};
-        for (int i = n; i < 4; ++i)
-            for (int a = 0; a < 3; ++a) bytes[a] |= LRL_EMPTY4_LO << (8 * i);      // empty slots: inverted boxes
-        for (int i = 0; i < n; ++i) {
-            for (int a = 0; a < 3; ++a) {
-                const double ql = std::floor((double(items[i].lo[a]) - double(origin[a])) / unit[a]);
-                const double qh = std::ceil((double(items[i].hi[a]) - double(origin[a])) / unit[a]);
-                bytes[a] |= uint32_t(std::min(255.0, std::max(0.0, ql))) << (8 * i);
-                bytes[3 + a] |= uint32_t(std::min(255.0, std::max(0.0, qh))) << (8 * i);
-            }
-            if (items[i].inner) {
-                refs[i] = recOf[items[i].ref];
-                work.push_back({items[i].ref, false, w.depth + 1});
-            } else refs[i] = LRL_REF_LEAF | items[i].ref;
-        }
-        q[0] = make_uint4(fb(origin[0]), fb(origin[1]), fb(origin[2]), expo[0] << 23);
-        q[1] = make_uint4(bytes[0], bytes[1], bytes[2], bytes[3]);
-        q[2] = make_uint4(bytes[4], bytes[5], refs[0], refs[1]);
-        q[3] = make_uint4(refs[2], refs[3], expo[1] << 23, expo[2] << 23);
-    }
-    depthOut = depth;
-    return out;
-}
-
 // ---- the four-wide tree in the order the rays walk it (lrl_layout_node4, lrl_build.hip) ----
-// subtree sizes of a host-built four-wide tree by record index: sizes[r] = four-wide nodes, sizes[recCount + r] = triangle leaves (a node's
-// items are records with larger indices: the binary tree is in pre-order)
-void node4Sizes(const std::vector<uint4>& n4, uint32_t recCount, std::vector<uint32_t>& sizes) {
-    sizes.assign(size_t(recCount) * 2, 0u);
-    for (uint32_t r = recCount; r-- > 0;) {
-        const uint32_t refs[4] = {n4[size_t(r) * 4 + 2].z, n4[size_t(r) * 4 + 2].w, n4[size_t(r) * 4 + 3].x, n4[size_t(r) * 4 + 3].y};
-        uint32_t sN = 1, sT = 0;
-        for (uint32_t ref : refs) {
-            if (ref != LRL_REF_NONE && !(ref & LRL_REF_LEAF)) { if (ref > r && ref < recCount) { sN += sizes[ref]; sT += sizes[size_t(recCount) + ref]; } }
-            else if ((ref >> LRL_PRIM_TYPE_SHIFT) == ((LRL_REF_LEAF >> LRL_PRIM_TYPE_SHIFT) | 2u)) ++sT;
-        }
-        sizes[r] = sN; sizes[size_t(recCount) + r] = sT;
-    }
-}
 int ensureLeafOrder(LrlContext* c, uint32_t recCount, uint32_t triCount) {
     int rc;
     if ((rc = ensure(c, c->layoutScratch, lrl_layout_scratch_bytes(recCount)))) return rc;
@@ -291,63 +82,28 @@ int ensureLeafOrder(LrlContext* c, uint32_t recCount, uint32_t triCount) {
 }
 void releaseLayoutTemporaries(LrlContext* c) {      // (hipFree waits for the device)
     if (c->nodes32Raw.bytes > (64u << 20)) release(c->nodes32Raw);
+    if (c->src4Raw.bytes > (64u << 20)) release(c->src4Raw);
     if (c->layoutScratch.bytes > (64u << 20)) release(c->layoutScratch);
-    if (c->layoutSizes.bytes > (64u << 20)) release(c->layoutSizes);
-}
-// a host-built four-wide tree (by record index) -> laid out in `dst`; assign: the triangles' places in triLeaf are made anew (posOfTri)
-int layoutFromHost(LrlContext* c, const std::vector<uint4>& node4, uint32_t recCount, uint32_t depth4, DevBuf& dst, bool assign, uint32_t triCount, uint32_t& wideNodes) {
-    std::vector<uint32_t> sizes;
-    node4Sizes(node4, recCount, sizes);
-    if (sizes[size_t(recCount)] > triCount) return fail(c, LRL_ERR_INVALID_ARG, "BVH: a triangle appears in more than one node");
-    int rc;
-    if ((rc = upload(c, c->nodes32Raw, node4.data(), node4.size() * sizeof(uint4)))) return rc;
-    if ((rc = upload(c, c->layoutSizes, sizes.data(), sizes.size() * 4))) return rc;
-    if ((rc = ensureLeafOrder(c, recCount, triCount))) return rc;
-    if ((rc = ensure(c, dst, size_t(sizes[0]) * 64))) return rc;
-    const uint32_t* sz = static_cast<const uint32_t*>(c->layoutSizes.p);
-    // (a caller's tree that names a triangle twice leaves a place of triLeaf without a record: an all-zero record is hit by no ray)
-    if (assign && triCount) HIP_TRY(c, hipMemsetAsync(c->triLeaf.p, 0, size_t(triCount) * 64, c->stream));
-    HIP_TRY(c, lrl_layout_node4(static_cast<const uint4*>(c->nodes32Raw.p), recCount, sz, sz + recCount, depth4 + 2, c->layoutScratch.p, static_cast<uint4*>(dst.p),
-                                static_cast<uint32_t*>(c->posOfTri.p), triCount, assign, c->stream));
-    HIP_TRY(c, hipStreamSynchronize(c->stream));      // `node4` and `sizes` are borrowed only for this call
-    wideNodes = sizes[0];
-    return LRL_OK;
+    if (c->callerScratch.bytes > (64u << 20)) release(c->callerScratch);
 }
 int gatherTriLeaf(LrlContext* c, uint32_t triCount) {
+    if (!triCount) return LRL_OK;
     HIP_TRY(c, lrl_launch_tri_leaf_gather(static_cast<const float4*>(c->triHot.p), static_cast<const uint32_t*>(c->posOfTri.p), 0, triCount,
                                           static_cast<float4*>(c->triLeaf.p), c->stream));
     return LRL_OK;
 }
 
-// the primitives' own boxes, for buildNode4 (callers' trees); both return whether a primitive left the box it had
-bool ownBoxPut(float* q, const float mn[3], const float mx[3]) {
-    bool left = false;
-    for (int a = 0; a < 3; ++a) {
-        left |= !(q[a] <= mn[a] && mx[a] <= q[3 + a]);
-        q[a] = mn[a]; q[3 + a] = mx[a];
-    }
-    return left;
-}
-bool ownTriangleBoxes(LrlContext* c, uint32_t first, uint32_t count, const LrlTriangle* tris) {
-    std::vector<float>& own = c->ownBox;
-    if (own.size() < size_t(first + count) * 6) return true;      // (not kept for this scene)
-    bool left = false;
-    for (uint32_t i = 0; i < count; ++i) {
-        const LrlTriangle& t = tris[i];
-        float mn[3], mx[3];
-        for (int a = 0; a < 3; ++a) {
-            mn[a] = std::min(t.p1[a], std::min(t.p2[a], t.p3[a]));
-            mx[a] = std::max(t.p1[a], std::max(t.p2[a], t.p3[a]));
-        }
-        left |= ownBoxPut(&own[size_t(first + i) * 6], mn, mx);
-    }
-    return left;
-}
-// Primitives changed under a caller's tree.  Its boxes are the contract again (the Pool demo never rebuilds: the water's leaf boxes
-// were made tall enough for every wave, Pool/Pool.cpp:250-263), until the next tree arrives.
-void ownBoxesStale(LrlContext* c) {
-    if (c->haveLoose) c->looseInUse = true;
-    c->pathsAtRest = 0;
+// A caller's four-wide tree that is fitted to its triangles (uploadCallerTree) follows them wherever they go, on the device and in stream
+// order (lrl_refit_node4): after every update of triangles and every water step.  The reference never refits: the Pool's leaf boxes were made
+// tall enough for every wave (/root/reference/Pool/Pool.cpp:250-263), and those boxes stay the contract here too (a triangle that leaves the box
+// the caller's tree gives it is bounded by that box, as for the reference).
+int refitOnDevice(LrlContext* c) {
+    if (!c->fitActive) return LRL_OK;
+    HIP_TRY(c, lrl_refit_node4(static_cast<uint4*>(c->nodes32.p), c->wideNodes, static_cast<const uint4*>(c->src4.p), static_cast<const LrlBVHNode*>(c->bvhDev.p),
+                               static_cast<const float4*>(c->primMin.p), static_cast<const float4*>(c->primMax.p), c->num.triangleNum, c->fitPad, c->node4Depth + 1u,
+                               c->refitScratch.p, c->stream));
+    c->refitted = true;
+    return LRL_OK;
 }
 
 // TrianglePre for [first, first+count): materials interned on the host, geometry on the device.
@@ -367,7 +123,7 @@ int runTrianglePre(LrlContext* c, uint32_t first, uint32_t count, const LrlTrian
     HIP_TRY(c, lrl_launch_triangle_pre(static_cast<const LrlTriangle*>(c->triStage.p), static_cast<const uint32_t*>(c->matStage.p), first,
                                        count, static_cast<float4*>(c->triHot.p), static_cast<LrlTriCold*>(c->triCold.p), static_cast<float4*>(c->triLeaf.p),
                                        c->leafOrder ? static_cast<const uint32_t*>(c->posOfTri.p) : nullptr, c->stream));
-    if (c->deviceBuilt && c->haveScene)      // keep the boxes current for lrl_scene_rebuild_bvh
+    if (c->triBoxes)      // keep the boxes current: for lrl_scene_rebuild_bvh, for the refit of a caller's tree
         HIP_TRY(c, lrl_launch_triangle_boxes(static_cast<const LrlTriangle*>(c->triStage.p), first, count, static_cast<float4*>(c->primMin.p),
                                              static_cast<float4*>(c->primMax.p), c->stream));
     HIP_TRY(c, hipStreamSynchronize(c->stream));   // `mat` and the caller's array are borrowed only for this call
@@ -505,7 +261,7 @@ int runDeviceBuild(LrlContext* c, uint32_t prims, uint32_t& recCount, uint32_t& 
         if ((rc = ensure(c, c->nodes32, size_t(info[3]) * 64))) return rc;
         if ((rc = ensureLeafOrder(c, recCount, triCount))) return rc;
         HIP_TRY(c, lrl_layout_node4(static_cast<const uint4*>(raw.p), recCount, sizes[0], sizes[1], info[1] + 1, c->layoutScratch.p, static_cast<uint4*>(c->nodes32.p),
-                                    static_cast<uint32_t*>(c->posOfTri.p), triCount, true, c->stream));
+                                    static_cast<uint32_t*>(c->posOfTri.p), triCount, true, nullptr, nullptr, c->stream));
         if ((rc = gatherTriLeaf(c, triCount))) return rc;
         c->leafOrder = true;
         c->wideNodes = info[3];
@@ -537,130 +293,61 @@ hipError_t noallocScratchFor(int device, void** out) {
     return hipSuccess;
 }
 
-// The caller's tree (pre-order 64-B own-box nodes) -> the two device layouts: 64-B inner records that hold both children's boxes, and the
-// four-wide compressed nodes.  Also lrl_scene_update_bvh.
-int uploadCallerTree(LrlContext* c, const LrlSceneView* s, uint32_t& recCount) {
-    int rc = LRL_OK;
-    recCount = 1;
-    const uint32_t N = s->bvhNodeNum;
-    std::vector<uint32_t> recOf(N, 0);
-    for (uint32_t i = 0; i < N; ++i) if (s->bvh[i].bound.leftChild) recOf[i] = recCount++;
-    auto refOf = [&](uint32_t i) -> uint32_t {
-        const LrlBVHNode& n = s->bvh[i];
-        if (n.bound.leftChild) return recOf[i];
-        return LRL_REF_LEAF | (n.geometry << LRL_PRIM_TYPE_SHIFT) | (n.geometryNum & LRL_PRIM_INDEX_MASK);
-    };
-    auto asf = [](uint32_t v) { float f; std::memcpy(&f, &v, 4); return f; };
-    std::vector<float4> packed(size_t(recCount) * 4);
-    {   // record 0: virtual parent of the root
-        const LrlBVHNode& r = s->bvh[0];
-        packed[0] = make_float4(r.bound.min[0], r.bound.min[1], r.bound.min[2], asf(refOf(0)));
-        packed[1] = make_float4(r.bound.max[0], r.bound.max[1], r.bound.max[2], asf(LRL_REF_NONE));
-        packed[2] = make_float4(0, 0, 0, asf(0));
-        packed[3] = make_float4(0, 0, 0, asf(0));
-    }
-    for (uint32_t i = 0; i < N; ++i) {
-        const LrlBVHNode& n = s->bvh[i];
-        if (!n.bound.leftChild) continue;
-        float4* q = &packed[size_t(recOf[i]) * 4];
-        const LrlBVHNode& l = s->bvh[i + 1];
-        uint32_t own = n.geometry ? ((n.geometry << LRL_PRIM_TYPE_SHIFT) | (n.geometryNum & LRL_PRIM_INDEX_MASK)) : 0u;
-        q[0] = make_float4(l.bound.min[0], l.bound.min[1], l.bound.min[2], asf(refOf(i + 1)));
-        if (n.bound.rightChild) {
-            const LrlBVHNode& r = s->bvh[n.bound.rightChild];
-            q[1] = make_float4(l.bound.max[0], l.bound.max[1], l.bound.max[2], asf(refOf(uint32_t(n.bound.rightChild))));
-            q[2] = make_float4(r.bound.min[0], r.bound.min[1], r.bound.min[2], asf(own));
-            q[3] = make_float4(r.bound.max[0], r.bound.max[1], r.bound.max[2], asf(n.axis));
-        } else {
-            q[1] = make_float4(l.bound.max[0], l.bound.max[1], l.bound.max[2], asf(LRL_REF_NONE));
-            q[2] = make_float4(0, 0, 0, asf(own));
-            q[3] = make_float4(0, 0, 0, asf(n.axis));
-        }
-    }
-    rc = upload(c, c->nodes, packed.data(), packed.size() * sizeof(float4));
-    if (rc) return rc;
-    HIP_TRY(c, hipStreamSynchronize(c->stream));
-    // the same tree collapsed to four children per node with 8-bit child boxes, for the FAST lean kernel (lrl_lean.inc)
-    uint32_t depth4 = 0;
-    FittedBoxes fitted;
-    const bool fit = fitOwnBoxes(s, c->ownBox, fitted);
-    std::vector<uint4> node4 = buildNode4(s, fit ? &fitted : nullptr, recOf, recCount, depth4);
-    const size_t tightened = fit ? fitted.count : 0;
-    fitted = FittedBoxes();
-    c->node4Depth = depth4;
-    const uint32_t triCount = s->num.triangleNum;
-    const bool layout = c->tuning.treeLayout == 0;
-    if (layout) {
-        if ((rc = layoutFromHost(c, node4, recCount, depth4, c->nodes32, true, triCount, c->wideNodes))) return rc;
-    } else {
-        if ((rc = upload(c, c->nodes32, node4.data(), node4.size() * sizeof(uint4)))) return rc;
-        HIP_TRY(c, hipStreamSynchronize(c->stream));
-        c->wideNodes = recCount;
-    }
-    c->leafOrder = layout;
-    c->haveLoose = c->looseInUse = false;
-    c->parkedTight = uint32_t(tightened);
-    if (fit) {      // the same tree with the caller's boxes, for when the primitives move under it (ownBoxesStale)
-        node4 = buildNode4(s, nullptr, recOf, recCount, depth4);
-        c->node4Depth = std::max(c->node4Depth, depth4);      // (the stacks are sized for either copy)
-        uint32_t looseNodes = 0;
-        if (layout) {
-            if ((rc = layoutFromHost(c, node4, recCount, depth4, c->nodes32Loose, false, triCount, looseNodes))) return rc;      // (the triangles keep the places the fitted tree gave them)
-        } else {
-            if ((rc = upload(c, c->nodes32Loose, node4.data(), node4.size() * sizeof(uint4)))) return rc;
-            HIP_TRY(c, hipStreamSynchronize(c->stream));
-        }
-        c->haveLoose = true;
-        if (c->callerTree.data() != s->bvh) c->callerTree.assign(s->bvh, s->bvh + s->bvhNodeNum);
-    } else if (c->callerTree.data() != s->bvh) { c->callerTree.clear(); c->callerTree.shrink_to_fit(); }
-    c->pathsAtRest = 0;
-    node4 = std::vector<uint4>();
-    releaseLayoutTemporaries(c);
-    if (c->tuning.debug) std::fprintf(stderr, "lrl: the four-wide tree bounds %zu primitives by their own boxes; %u of %u node slots in use\n", tightened, c->wideNodes, recCount);
-    return LRL_OK;
-}
-
-// A scene whose triangles moved under the caller's tree is fitted again when the rendering since the move is worth it: the fit costs about
-// 0.2 us per node of the tree (on the host) and saves a third of a frame that costs about 0.5 ns per path, so it is done before the render
-// that takes the paths since the move past 2048 per node (the Pool: 13.7 M paths, seven samples of 1080p: the paused Pool a few frames after
-// the init-time sync of its water, Pool/Pool.cpp:648-650; a 64-sample frame right after a water step; never a loop of one-sample frames
-// with a step each): the water's triangles, which moved on the device, are read back for
-// their boxes (the others' are kept current by the update calls), and the fitted copy of the four-wide tree is made anew.  Renders in flight
-// walk the other copy.
-int refitAtRest(LrlContext* c, uint64_t paths) {
-    if (!c->looseInUse || c->callerTree.empty() || c->deviceBuilt || c->tuning.deterministic) return LRL_OK;
-    c->pathsAtRest += paths;
-    if (c->pathsAtRest < 2048ull * c->callerTree.size()) return LRL_OK;
-    if (int rc0 = orderAfterRenders(c)) return rc0;      // (a frame in flight on another stream may still walk the copy that is about to be replaced)
-    HIP_TRY(c, hipStreamSynchronize(c->stream));
-    if (c->waterGX && c->ownBox.size() >= size_t(c->num.triangleNum) * 6) {
-        const uint32_t count = 2u * (c->waterGX - 1) * (c->waterGY - 1);
-        std::vector<LrlTriangle> t(count);
-        HIP_TRY(c, hipStreamSynchronize(c->stream));
-        HIP_TRY(c, hipMemcpy(t.data(), c->waterTris.p, size_t(count) * sizeof(LrlTriangle), hipMemcpyDeviceToHost));
-        (void)ownTriangleBoxes(c, c->waterFirst, count, t.data());
-    }
-    LrlSceneView v{};
-    v.num = c->num; v.bvh = c->callerTree.data(); v.bvhNodeNum = uint32_t(c->callerTree.size());
-    uint32_t recCount = 1;
-    std::vector<uint32_t> recOf(v.bvhNodeNum, 0);
-    for (uint32_t i = 0; i < v.bvhNodeNum; ++i) if (v.bvh[i].bound.leftChild) recOf[i] = recCount++;
-    FittedBoxes fitted;
-    if (!fitOwnBoxes(&v, c->ownBox, fitted)) { c->pathsAtRest = 0; c->callerTree.clear(); c->callerTree.shrink_to_fit(); return LRL_OK; }      // (nothing to gain any more)
-    uint32_t depth4 = 0;
-    std::vector<uint4> node4 = buildNode4(&v, &fitted, recOf, recCount, depth4);
+// The caller's tree (pre-order 64-B own-box nodes, validated) -> the two device layouts: 64-B inner records that hold both children's boxes, and
+// the four-wide compressed nodes, fitted to the triangles' own boxes where that pays, in the order the rays walk them.  All of it on the device
+// (lrl_caller_tree, lrl_layout_node4); the triangles are there already.  Also lrl_scene_update_bvh.
+int uploadCallerTree(LrlContext* c, const LrlBVHNode* bvh, uint32_t N, uint32_t recCount, uint32_t depth) {
     int rc;
-    if (c->leafOrder) rc = layoutFromHost(c, node4, recCount, depth4, c->nodes32, false, c->num.triangleNum, c->wideNodes);      // (the triangles stay where they are in triLeaf)
-    else {
-        rc = upload(c, c->nodes32, node4.data(), node4.size() * sizeof(uint4));
-        if (!rc) HIP_TRY(c, hipStreamSynchronize(c->stream));
+    const uint32_t triCount = c->num.triangleNum;
+    const bool layout = c->tuning.treeLayout == 0;
+    c->fitActive = false;
+    c->leafOrder = false;
+    c->parkedTight = 0;
+    if ((rc = upload(c, c->bvhDev, bvh, size_t(N) * sizeof(LrlBVHNode)))) return rc;
+    DevBuf& raw = layout ? c->nodes32Raw : c->nodes32;
+    DevBuf& srcRaw = layout ? c->src4Raw : c->src4;
+    if ((rc = ensure(c, c->nodes, size_t(recCount) * 64))) return rc;
+    if ((rc = ensure(c, raw, size_t(recCount) * 64))) return rc;
+    if ((rc = ensure(c, srcRaw, size_t(recCount) * 16))) return rc;
+    if ((rc = ensure(c, c->callerScratch, lrl_caller_tree_scratch_bytes(N, recCount)))) return rc;
+    if ((rc = ensure(c, c->buildInfo, 256))) return rc;
+    float scale = 0.0f;       // of the coordinates the slab arithmetic works with
+    for (int a = 0; a < 3; ++a) scale = std::max(scale, std::max(std::fabs(bvh[0].bound.min[a]), std::fabs(bvh[0].bound.max[a])));
+    c->fitPad = std::isfinite(scale) ? std::ldexp(scale, -14) : 0.0f;
+    const bool own = c->triBoxes && triCount;
+    const uint32_t* sizes[2] = {nullptr, nullptr};
+    HIP_TRY(c, lrl_caller_tree(static_cast<const LrlBVHNode*>(c->bvhDev.p), N, recCount, depth + 1u, own ? static_cast<const float4*>(c->primMin.p) : nullptr,
+                               own ? static_cast<const float4*>(c->primMax.p) : nullptr, triCount, c->fitPad, c->callerScratch.p, static_cast<float4*>(c->nodes.p),
+                               static_cast<uint4*>(raw.p), static_cast<uint4*>(srcRaw.p), sizes, static_cast<uint32_t*>(c->buildInfo.p), c->stream));
+    uint32_t info[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    HIP_TRY(c, hipMemcpyAsync(info, c->buildInfo.p, sizeof(info), hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));      // (`bvh` is borrowed only for this call)
+    if (info[6] == 0 || info[0] == 0 || info[3] == 0 || info[3] > recCount) return fail(c, LRL_ERR_DEVICE, "the caller's tree did not reach its root on the device");
+    if (info[4] > triCount) return fail(c, LRL_ERR_INVALID_ARG, "BVH: a triangle appears in more than one node");
+    c->node4Depth = info[0];
+    c->wideNodes = recCount;
+    if (layout) {
+        if ((rc = ensure(c, c->nodes32, size_t(info[3]) * 64))) return rc;
+        if ((rc = ensure(c, c->src4, size_t(info[3]) * 16))) return rc;
+        if ((rc = ensureLeafOrder(c, recCount, triCount))) return rc;
+        // (a caller's tree that leaves a triangle out leaves a place of triLeaf without a record: an all-zero record is hit by no ray)
+        if (triCount) HIP_TRY(c, hipMemsetAsync(c->triLeaf.p, 0, size_t(triCount) * 64, c->stream));
+        HIP_TRY(c, lrl_layout_node4(static_cast<const uint4*>(raw.p), recCount, sizes[0], sizes[1], info[0] + 1u, c->layoutScratch.p, static_cast<uint4*>(c->nodes32.p),
+                                    static_cast<uint32_t*>(c->posOfTri.p), triCount, true, static_cast<const uint4*>(srcRaw.p), static_cast<uint4*>(c->src4.p), c->stream));
+        if ((rc = gatherTriLeaf(c, triCount))) return rc;
+        c->leafOrder = true;
+        c->wideNodes = info[3];
+        HIP_TRY(c, hipStreamSynchronize(c->stream));
     }
-    if (rc) return rc;
-    c->node4Depth = std::max(c->node4Depth, depth4);
-    c->parkedTight = uint32_t(fitted.count);
-    c->looseInUse = false;
-    c->pathsAtRest = 0;
-    if (c->tuning.debug) std::fprintf(stderr, "lrl: the scene is at rest: the four-wide tree is fitted again (%zu own boxes)\n", fitted.count);
+    releaseLayoutTemporaries(c);
+    c->fitActive = info[7] != 0;
+    c->parkedTight = info[5];
+    c->refitted = false;
+    if (c->fitActive) {
+        if ((rc = ensure(c, c->refitScratch, lrl_refit_scratch_bytes(c->wideNodes)))) return rc;
+    } else { release(c->bvhDev); release(c->src4); release(c->refitScratch); }      // (nothing follows the triangles)
+    if (c->tuning.debug) std::fprintf(stderr, "lrl: the four-wide tree bounds %u primitives by their own boxes (%u would gain, nested %d); %u of %u node slots in use\n",
+                                      info[5], info[1], info[2] ? 0 : 1, c->wideNodes, recCount);
     return LRL_OK;
 }
 
@@ -690,30 +377,22 @@ int lrl_scene_upload(LrlContext* c, const LrlSceneView* s) {
     if (s->texLayers && (!s->texBGR || !s->texWidth || !s->texHeight)) return fail(c, LRL_ERR_INVALID_ARG, "texture array incomplete");
     if (s->cubeSize) for (int i = 0; i < 6; ++i) if (!s->cubeBGR[i]) return fail(c, LRL_ERR_INVALID_ARG, "cube face missing");
     uint32_t depth = 0;
-    int rc = deviceBuild ? LRL_OK : validateBVH(c, s, depth);
+    uint32_t recCount = 1;
+    int rc = deviceBuild ? LRL_OK : validateBVH(c, s, depth, recCount);
     if (rc) return rc;
     c->haveScene = false;
     c->deviceBuilt = false;
     c->waterGX = c->waterGY = 0;      // a new scene: lrl_water_init again
 
-    // nodes: the reference's 64-B own-box records -> 64-B inner records that hold both children's boxes
-    uint32_t recCount = 1;
-    c->ownBox.clear(); c->ownBox.shrink_to_fit();
-    if (deviceBuild) { c->callerTree.clear(); c->callerTree.shrink_to_fit(); }
-    c->haveLoose = c->looseInUse = false;
+    c->fitActive = false;
     c->parkedTight = 0;
-    c->leafOrder = false;      // (the device build lays its tree out after the triangles are there; a caller's tree before: TrianglePre then writes both copies)
-    if (!deviceBuild) {
-        if (g.triangleNum && s->trianglesOrigin) {
-            c->ownBox.assign(size_t(g.triangleNum) * 6, 0.0f);
-            (void)ownTriangleBoxes(c, 0, g.triangleNum, s->trianglesOrigin);
-        }
-    }
-    if (!deviceBuild && (rc = uploadCallerTree(c, s, recCount))) return rc;
-    if (!deviceBuild && c->tuning.debug) std::fprintf(stderr, "lrl: binary nodes %u (depth %u), four-wide tree depth %u\n", s->bvhNodeNum, depth, c->node4Depth);
-    if (deviceBuild) {
-        if ((rc = ensure(c, c->primMin, size_t(primTotal) * 16))) return rc;
-        if ((rc = ensure(c, c->primMax, size_t(primTotal) * 16))) return rc;
+    c->leafOrder = false;      // (the tree is made and laid out after the triangles are there; TrianglePre writes both copies of their records from then on)
+    // the triangles' own boxes: what the device build sorts, what a caller's tree is fitted to (trianglesGPU does not give the corners)
+    c->triBoxes = g.triangleNum && s->trianglesOrigin;
+    if (deviceBuild || c->triBoxes) {
+        const uint64_t boxes = deviceBuild ? primTotal : uint64_t(g.triangleNum);
+        if ((rc = ensure(c, c->primMin, size_t(boxes) * 16))) return rc;
+        if ((rc = ensure(c, c->primMax, size_t(boxes) * 16))) return rc;
     }
     c->materialTable.clear();
     c->materialIndex.clear();
@@ -735,13 +414,8 @@ int lrl_scene_upload(LrlContext* c, const LrlSceneView* s) {
             const uint32_t slab = 1u << 22;
             for (uint32_t first = 0; first < g.triangleNum; first += slab) {
                 const uint32_t cnt = std::min(slab, g.triangleNum - first);
-                rc = runTrianglePre(c, first, cnt, s->trianglesOrigin + first);
+                rc = runTrianglePre(c, first, cnt, s->trianglesOrigin + first);      // (and their boxes)
                 if (rc) return rc;
-                if (deviceBuild) {      // the slab is still in the staging buffer
-                    HIP_TRY(c, lrl_launch_triangle_boxes(static_cast<const LrlTriangle*>(c->triStage.p), first, cnt, static_cast<float4*>(c->primMin.p),
-                                                         static_cast<float4*>(c->primMax.p), c->stream));
-                    HIP_TRY(c, hipStreamSynchronize(c->stream));
-                }
             }
         } else {
             std::vector<float4> hot(size_t(g.triangleNum) * 4);
@@ -763,7 +437,6 @@ int lrl_scene_upload(LrlContext* c, const LrlSceneView* s) {
             if (rc) return rc;
             rc = upload(c, c->materials, c->materialTable.data(), c->materialTable.size() * sizeof(LrlColor));
             if (rc) return rc;
-            if (c->leafOrder && (rc = gatherTriLeaf(c, g.triangleNum))) return rc;
             HIP_TRY(c, hipStreamSynchronize(c->stream));
         }
     }
@@ -794,7 +467,10 @@ int lrl_scene_upload(LrlContext* c, const LrlSceneView* s) {
         c->cubeSize = s->cubeSize;
     } else if ((rc = ensure(c, c->cube, 4))) return rc;
     HIP_TRY(c, hipStreamSynchronize(c->stream));
-    if (deviceBuild) {
+    if (!deviceBuild) {
+        if ((rc = uploadCallerTree(c, s->bvh, s->bvhNodeNum, recCount, depth))) return rc;
+        if (c->tuning.debug) std::fprintf(stderr, "lrl: binary nodes %u (depth %u), four-wide tree height %u\n", s->bvhNodeNum, depth, c->node4Depth);
+    } else {
         if ((rc = buildOnDevice(c, s, uint32_t(primTotal), recCount, depth))) return rc;
         if (c->tuning.debug) std::fprintf(stderr, "lrl: device-built tree over %llu primitives: %u records, height %u, four-wide height %u\n",
                                                    (unsigned long long)primTotal, recCount, depth, c->node4Depth);
@@ -814,8 +490,8 @@ int lrl_scene_update_triangles(LrlContext* c, uint32_t first, uint32_t count, co
     if (uint64_t(first) + count > c->num.triangleNum) return fail(c, LRL_ERR_INVALID_ARG, "triangle range out of bounds");
     HIP_TRY(c, hipSetDevice(c->device));
     if (int rc0 = orderAfterRenders(c)) return rc0;
-    if (count && ownTriangleBoxes(c, first, count, tris)) ownBoxesStale(c);      // (the same triangles again, as the Pool demo sends them every frame: nothing moved)
-    return runTrianglePre(c, first, count, tris);
+    if (int rc = runTrianglePre(c, first, count, tris)) return rc;
+    return count ? refitOnDevice(c) : LRL_OK;
 }
 
 int lrl_scene_update_triangles_noalloc(LrlContext* c, uint32_t first, uint32_t count, const LrlTriangle* tris) {
@@ -839,7 +515,6 @@ int lrl_scene_update_triangles_noalloc(LrlContext* c, uint32_t first, uint32_t c
         pinMat[i] = it->second;
     }
     std::memcpy(pinTris, tris, size_t(count) * sizeof(LrlTriangle));
-    if (ownTriangleBoxes(c, first, count, tris)) ownBoxesStale(c);      // (written in place: the vector has its size since the scene came)
     unsigned char* const area = static_cast<unsigned char*>(c->noallocScratch);
     LrlTriangle* const stageTris = reinterpret_cast<LrlTriangle*>(area);
     uint32_t* const stageMat = reinterpret_cast<uint32_t*>(area + size_t(LRL_NOALLOC_MAX_TRIANGLES) * sizeof(LrlTriangle));
@@ -848,8 +523,9 @@ int lrl_scene_update_triangles_noalloc(LrlContext* c, uint32_t first, uint32_t c
     HIP_TRY(c, hipMemcpyAsync(stageMat, pinMat, size_t(count) * 4, hipMemcpyHostToDevice, c->stream));
     HIP_TRY(c, lrl_launch_triangle_pre(stageTris, stageMat, first, count, static_cast<float4*>(c->triHot.p), static_cast<LrlTriCold*>(c->triCold.p),
                                        static_cast<float4*>(c->triLeaf.p), c->leafOrder ? static_cast<const uint32_t*>(c->posOfTri.p) : nullptr, c->stream));
-    if (c->deviceBuilt)      // keep the boxes current for lrl_scene_rebuild_bvh
+    if (c->triBoxes)      // keep the boxes current: for lrl_scene_rebuild_bvh, for the refit of a caller's tree
         HIP_TRY(c, lrl_launch_triangle_boxes(stageTris, first, count, static_cast<float4*>(c->primMin.p), static_cast<float4*>(c->primMax.p), c->stream));
+    if (int rcFit = refitOnDevice(c)) return rcFit;      // (its scratch was allocated when the tree came)
     HIP_TRY(c, hipStreamSynchronize(c->stream));   // the caller's array is borrowed only for this call; the staging area is free again
     return LRL_OK;
 }
@@ -910,13 +586,12 @@ int lrl_scene_update_bvh(LrlContext* c, const LrlBVHNode* bvh, uint32_t bvhNodeN
     LrlSceneView v{};
     v.num = c->num; v.bvh = bvh; v.bvhNodeNum = bvhNodeNum;
     uint32_t depth = 0, recCount = 1;
-    int rc = validateBVH(c, &v, depth);
+    int rc = validateBVH(c, &v, depth, recCount);
     if (rc) return rc;
     if ((rc = orderAfterRenders(c))) return rc;
     HIP_TRY(c, hipStreamSynchronize(c->stream));      // frames in flight walk the old tree
     c->haveScene = false;                             // (a failed upload leaves no half-written tree in use)
-    if ((rc = uploadCallerTree(c, &v, recCount))) return rc;
-    if (c->leafOrder && (rc = gatherTriLeaf(c, c->num.triangleNum))) return rc;      // the new tree has its own order of leaves
+    if ((rc = uploadCallerTree(c, bvh, bvhNodeNum, recCount, depth))) return rc;      // (the new tree has its own order of leaves: triLeaf is made anew)
     c->nodeNum = bvhNodeNum; c->recNum = recCount; c->bvhDepth = depth;
     c->handoverThr.clear(); c->feedbackTick = 0; c->contIters = 0;
     c->phasedTrial.state = 0; c->phasedTrial.signature = 0;
@@ -1002,19 +677,15 @@ int lrl_water_step(LrlContext* c, uint32_t substeps) {
     HIP_TRY(c, hipSetDevice(c->device));
     if (int rc0 = orderAfterRenders(c)) return rc0;
     const uint32_t count = 2u * (c->waterGX - 1) * (c->waterGY - 1);
-    if (c->ownBox.size() >= size_t(c->waterFirst + count) * 6) {      // where the water's triangles are now is known on the device only
-        for (uint32_t i = 0; i < count; ++i) { float* q = &c->ownBox[size_t(c->waterFirst + i) * 6]; q[0] = 1.0f; q[3] = 0.0f; }
-    }
-    ownBoxesStale(c);
     HIP_TRY(c, lrl_launch_water_run(static_cast<float4*>(c->waterPoints.p), c->waterGX, c->waterGY, c->waterK, c->waterDt, substeps,
                                     static_cast<LrlTriangle*>(c->waterTris.p), c->stream));
     HIP_TRY(c, lrl_launch_triangle_pre(static_cast<const LrlTriangle*>(c->waterTris.p), static_cast<const uint32_t*>(c->waterMat.p), c->waterFirst, count,
                                        static_cast<float4*>(c->triHot.p), static_cast<LrlTriCold*>(c->triCold.p), static_cast<float4*>(c->triLeaf.p),
                                        c->leafOrder ? static_cast<const uint32_t*>(c->posOfTri.p) : nullptr, c->stream));
-    if (c->deviceBuilt)      // keep the boxes current for lrl_scene_rebuild_bvh
+    if (c->triBoxes)      // keep the boxes current: for lrl_scene_rebuild_bvh, for the refit of a caller's tree
         HIP_TRY(c, lrl_launch_triangle_boxes(static_cast<const LrlTriangle*>(c->waterTris.p), c->waterFirst, count, static_cast<float4*>(c->primMin.p),
                                              static_cast<float4*>(c->primMax.p), c->stream));
-    return LRL_OK;
+    return refitOnDevice(c);
 }
 
 int lrl_water_read(LrlContext* c, LrlWaterPoint* points, LrlTriangle* triangles) {

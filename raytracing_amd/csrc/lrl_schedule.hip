@@ -349,7 +349,6 @@ static int renderImpl(LrlContext* c, const LrlRenderParams* p, float* rgbaDev, u
     const uint32_t spp = p->spp;
     uint32_t s0 = p->sampleBegin, s1 = p->sampleEnd;
     if (s0 == 0 && s1 == 0) s1 = spp;
-    if (int rcFit = refitAtRest(c, uint64_t(s1 - s0) * c->width * rows)) return rcFit;
     // per-sample camera: the jitter is the shear of `trans`; computed here in float like the host helper
     std::vector<LrlTrans> tr(spp, c->trans);
     if (p->jitter) {

@@ -1036,9 +1036,11 @@ def test_moving_spheres_and_lights_like_movement_run(tracer):
 def test_parked_primitives_are_bounded_by_their_own_boxes(tracer, pool_model):
     """The reference's builder parks a primitive in most inner nodes, and its shader tests it whenever the ray enters that node's box
     (a whole subtree's); the Pool's leaf boxes are as tall as the highest wave.  The four-wide tree of the FAST kernels is fitted to
-    the primitives' own boxes while the scene is as it was uploaded: the same frame, bit for bit, as with the caller's boxes alone.  Once a primitive leaves the box it had, the caller's
-    boxes alone decide again (the Pool's water moves under a fixed tree whose leaf boxes were made tall enough, Pool/Pool.cpp:250-263):
-    a parked triangle moved inside its node's box, without a new tree, must be found where the oracle finds it on that tree."""
+    the primitives' own boxes, and refitted on the device whenever triangles change (lrl_refit_node4): the same frame, bit for bit, as
+    with the caller's boxes alone.  The caller's boxes stay the contract (the Pool's water moves under a fixed tree whose leaf boxes were
+    made tall enough, Pool/Pool.cpp:250-263): a parked triangle moved inside its node's box, without a new tree, must be found where the
+    oracle finds it on that tree; one moved out of its node's box is bounded by that box, as for the reference, and is seen only where
+    the oracle sees it through the old tree."""
     g = load_golden("pool_viewB_192")
     W, H = g["width"], g["height"]
     view = pool_model.scene_view()
@@ -1049,36 +1051,56 @@ def test_parked_primitives_are_bounded_by_their_own_boxes(tracer, pool_model):
     tracer.scene_upload(view)
     tracer.set_camera(g["trans"], W, H)
     tracer.set_decay_origin((0, 0, 0, 1))
-    assert tracer.scene_info()["ownBoxes"] >= len(parked)
+    own = tracer.scene_info()["ownBoxes"]
+    assert own >= len(parked)
     kw = dict(max_depth=8, variant=abi.VARIANT_POOL, mode=abi.MODE_FAST)
     tight = tracer.render(**kw)
     tracer.update_triangles(0, tris)                          # the same triangles again, as Pool sends them every frame: nothing moved
-    assert tracer.scene_info()["ownBoxes"] >= len(parked)
+    assert tracer.scene_info()["ownBoxes"] == own             # (now the refit's count: the same rule, the same boxes)
+    same = tracer.render(**kw)
+    assert np.array_equal(same[1], tight[1]) and np.array_equal(same[0].view(np.uint32), tight[0].view(np.uint32))
     # a parked water triangle near the middle of the view, lowered by less than its node's box allows
     nodes = parked[bvh["geometryNum"][parked] < 2 * 47 * 47]
     pick = nodes[np.argmax(bvh["max"][nodes, 2] - bvh["min"][nodes, 2] > 0.05)]
     ti = int(bvh["geometryNum"][pick])
+
+    def oracle_with(moved):
+        all_tris = tris.copy(); all_tris[ti] = moved[0]
+        m2 = scenes.pool()
+        _host_records(m2.scene_view().trianglesOrigin, len(all_tris), abi.TRIANGLE)[:] = all_tris      # the oracle: moved triangle, the old tree
+        return O.render(m2.scene_view(), g["trans"], W, H, max_depth=8, variant=abi.VARIANT_POOL, threads=8)
+
     moved = tris[ti:ti + 1].copy()
     for f in ("p1", "p2", "p3"):
         moved[f][:, 2] -= 0.04
     assert all((moved[f][0] >= bvh["min"][pick]).all() and (moved[f][0] <= bvh["max"][pick]).all() for f in ("p1", "p2", "p3"))
     tracer.update_triangles(ti, moved)
-    assert tracer.scene_info()["ownBoxes"] == 0
+    assert tracer.scene_info()["ownBoxes"] == own             # still bounded by its own box, where it is now
     got = tracer.render(**kw)
     par = tracer.render(max_depth=8, variant=abi.VARIANT_POOL)
-    all_tris = tris.copy(); all_tris[ti] = moved[0]
-    m2 = scenes.pool()
-    _host_records(m2.scene_view().trianglesOrigin, len(all_tris), abi.TRIANGLE)[:] = all_tris      # the oracle: moved triangle, the old tree
-    oimg, ohits, _ = O.render(m2.scene_view(), g["trans"], W, H, max_depth=8, variant=abi.VARIANT_POOL, threads=8)
+    oimg, ohits, _ = oracle_with(moved)
     assert (par[1] == ohits).all(axis=-1).mean() >= ID_BAR and (got[1] == ohits).all(axis=-1).mean() >= ID_BAR
     check_image(got[0], oimg, abi.MODE_FAST, "parked triangle moved under the caller's tree")
     assert not np.array_equal(got[0], tight[0])
-    tracer.update_triangles(ti, tris[ti:ti + 1])              # back where it was: still the caller's boxes alone, and the same frame
-    assert tracer.scene_info()["ownBoxes"] == 0
-    loose = tracer.render(**kw)
-    assert np.array_equal(loose[1], tight[1]) and np.array_equal(loose[0].view(np.uint32), tight[0].view(np.uint32))
+    # out of its node's box (raised above it): the caller's box bounds it again, and decides which rays meet it
+    out = tris[ti:ti + 1].copy()
+    lift = np.float32(bvh["max"][pick, 2] - min(out[f][0, 2] for f in ("p1", "p2", "p3")) + 0.02)
+    for f in ("p1", "p2", "p3"):
+        out[f][:, 2] += lift
+    assert all(out[f][0, 2] > bvh["max"][pick, 2] for f in ("p1", "p2", "p3"))
+    tracer.update_triangles(ti, out)
+    assert tracer.scene_info()["ownBoxes"] == own - 1
+    got = tracer.render(**kw)
+    par = tracer.render(max_depth=8, variant=abi.VARIANT_POOL)
+    oimg, ohits, _ = oracle_with(out)
+    assert (par[1] == ohits).all(axis=-1).mean() >= ID_BAR and (got[1] == ohits).all(axis=-1).mean() >= ID_BAR
+    check_image(got[0], oimg, abi.MODE_FAST, "parked triangle moved out of its node's box")
+    tracer.update_triangles(ti, tris[ti:ti + 1])              # back where it was: the same boxes, the same frame
+    assert tracer.scene_info()["ownBoxes"] == own
+    back = tracer.render(**kw)
+    assert np.array_equal(back[1], tight[1]) and np.array_equal(back[0].view(np.uint32), tight[0].view(np.uint32))
     tracer.update_bvh(view.bvh, view.bvhNodeNum)              # a new tree: own boxes again
-    assert tracer.scene_info()["ownBoxes"] >= len(parked)
+    assert tracer.scene_info()["ownBoxes"] == own
     again = tracer.render(**kw)
     assert np.array_equal(again[0].view(np.uint32), tight[0].view(np.uint32))
     # the other kinds keep the caller's boxes (the kernels' cold path is cheapest taken by a wave's lanes together, on arrival at the node):
@@ -1104,40 +1126,6 @@ def test_parked_primitives_are_bounded_by_their_own_boxes(tracer, pool_model):
     tracer.update_primitives(abi.PRIM_SPHERE, 0, sph)
     c = tracer.render(max_depth=6, mode=abi.MODE_FAST)
     assert np.array_equal(a[1], c[1]) and np.array_equal(a[0].view(np.uint32), c[0].view(np.uint32))
-
-
-def test_refit_after_a_host_side_triangle_update(pool_model):
-    """lrl_scene_update_triangles with moved vertices keeps the triangles' own boxes current on the host, so the fit that follows (here:
-    one frame large enough to pay for it) needs nothing from the device: a parked water triangle lowered inside its node's box is found
-    where the oracle finds it, on the fitted tree."""
-    from raytracing_amd import tracer as T
-    g = load_golden("pool_viewB_192")
-    tris = pool_model.arrays()["triangles"]
-    bvh = pool_model.arrays()["bvh"]
-    parked = np.flatnonzero((bvh["leftChild"] != 0) & (bvh["geometry"] == 2) & (bvh["geometryNum"] < 2 * 47 * 47))
-    pick = parked[np.argmax(bvh["max"][parked, 2] - bvh["min"][parked, 2] > 0.05)]
-    ti = int(bvh["geometryNum"][pick])
-    moved = tris[ti:ti + 1].copy()
-    for f in ("p1", "p2", "p3"):
-        moved[f][:, 2] -= 0.04
-    W = H = 512
-    jit = host.jitter_table(64)                                   # 16.8 M paths: more than 2048 per node of the Pool's tree
-    t = T.Tracer(0)
-    try:
-        t.scene_upload(pool_model.scene_view())
-        t.set_camera(g["trans"], W, H)
-        t.set_decay_origin((0, 0, 0, 1))
-        fitted = t.scene_info()["ownBoxes"]
-        t.update_triangles(ti, moved)
-        assert t.scene_info()["ownBoxes"] == 0
-        img, hits = t.render(max_depth=8, variant=abi.VARIANT_POOL, mode=abi.MODE_FAST, jitter=jit)
-        assert t.scene_info()["ownBoxes"] == fitted                # fitted again, before that frame
-    finally:
-        t.close()
-    all_tris = tris.copy(); all_tris[ti] = moved[0]
-    oimg, ohits, _ = O.render(view_with(pool_model, all_tris), host.sample_trans(g["trans"], jit), W, H, max_depth=8, variant=abi.VARIANT_POOL, threads=16)
-    assert (hits == ohits).all(axis=-1).mean() >= ID_BAR
-    check_image(img, oimg, abi.MODE_FAST, "fitted again after a host-side update")
 
 
 def test_oversized_boxes_of_a_callers_tree_are_fitted(tracer, bunny0_model):
@@ -1179,12 +1167,11 @@ def test_oversized_boxes_of_a_callers_tree_are_fitted(tracer, bunny0_model):
     assert (got[1] == ohits).all(axis=-1).mean() >= ID_BAR
 
 
-def test_a_moved_scene_is_fitted_again_when_it_pays(pool_model):
+def test_a_callers_tree_follows_the_water(pool_model):
     """The Pool's binding syncs the water's triangles on the device once at start-up (lrl_water_init + lrl_water_step(0),
-    Pool/Pool.cpp:648-650): they have moved under the caller's tree, so its boxes alone decide.  Once the frames rendered since the move
-    are worth the fit (2048 paths per node of the tree), the library reads the water's triangles back, fits the four-wide tree to where
-    they are now and goes on with that: the same frames, before and after, at rest and after real waves (checked against the oracle on
-    the moved triangles).  A large frame right after a move is fitted at once.
+    Pool/Pool.cpp:648-650) and steps them every frame: they move under the caller's tree.  The four-wide tree is refitted to where they
+    are by a kernel queued behind the step (lrl_refit_node4; nothing is read back, no frame waits for the host): the frames are the
+    oracle's on the moved triangles, at rest and after real waves, and the same as the PARITY kernels' walk of the caller's own boxes.
     "The same" is bit for bit except at floating-point tie edges: of this view's 36 864 x 64 primary rays one passes 8e-7 (barycentric) from
     the edge shared by triangles 1120 and 1167; FAST arithmetic finds it inside both, 1167 an ulp nearer.  The caller's leaf box of 1167
     ends exactly on that edge and the slab arithmetic's rounding turns the ray away, so the caller's boxes give 1120 (as the oracle does);
@@ -1194,15 +1181,11 @@ def test_a_moved_scene_is_fitted_again_when_it_pays(pool_model):
     k, dt = scenes.POOL_WATER
     nw = 2 * (gx - 1) * (gy - 1)
     tris = pool_model.arrays()["triangles"]
-    nodes = len(pool_model.arrays()["bvh"])
     w0 = scenes.pool_water_points(pool_model)
     g = load_golden("pool_viewB_192")
     W, H, spp = g["width"], g["height"], 64
     jit = host.jitter_table(spp)
     kw = dict(max_depth=8, variant=abi.VARIANT_POOL, mode=abi.MODE_FAST, jitter=jit)
-    per_render = W * H * spp
-    need = -(-2048 * nodes // per_render)                     # renders until the fit pays
-    assert 3 <= need <= 12
     t = T.Tracer(0)
     try:
         t.scene_upload(pool_model.scene_view())
@@ -1213,26 +1196,24 @@ def test_a_moved_scene_is_fitted_again_when_it_pays(pool_model):
         t.water_init(gx, gy, k, dt, w0, 0, tris[:nw])
         for steps in (0, 200):
             t.water_step(steps)
-            first = None
-            for i in range(need + 1):
-                # the render that takes the paths since the move past the bar fits the tree first
-                assert (t.scene_info()["ownBoxes"] == 0) == (i < need), (steps, i)
-                again = t.render(**kw)
-                first = first or again
-                moved = int((again[0].view(np.uint32) != first[0].view(np.uint32)).any(axis=-1).sum())
-                assert np.array_equal(again[1], first[1]) and moved <= (2 if i >= need - 1 else 0), (steps, i, moved)      # (render need - 1 is the first on the fitted tree)
-            assert t.scene_info()["ownBoxes"] >= fitted - 50
+            first = t.render(**kw)
+            assert t.scene_info()["ownBoxes"] >= fitted - 50              # (a wave may lift a corner out of a box made for the water at rest)
+            again = t.render(**kw)
+            assert np.array_equal(again[1], first[1]) and np.array_equal(again[0].view(np.uint32), first[0].view(np.uint32)), steps
             ow = O.water_run(w0, gx, gy, k, dt, steps) if steps else w0
             ot = O.water_sync(ow, gx, gy, tris)
             oimg, ohits, _ = O.render(view_with(pool_model, ot), host.sample_trans(g["trans"], jit), W, H, max_depth=8, variant=abi.VARIANT_POOL, threads=8)
-            assert_ids(again[1], ohits, view_with(pool_model, ot), sample0(g["trans"], jit), W, H, ("the Pool fitted again", steps))
-            check_image(again[0], oimg, abi.MODE_FAST, ("the Pool fitted again", steps))
-        # a frame that is worth the fit by itself
-        t.water_step(50)
-        assert t.scene_info()["ownBoxes"] == 0
-        t.set_camera(g["trans"], 4 * W, 4 * H)
-        big = t.render(**kw)
-        assert t.scene_info()["ownBoxes"] >= fitted - 50
+            assert_ids(again[1], ohits, view_with(pool_model, ot), sample0(g["trans"], jit), W, H, ("the Pool's tree follows the water", steps))
+            check_image(again[0], oimg, abi.MODE_FAST, ("the Pool's tree follows the water", steps))
+        # many small steps, a frame each, nothing waited for in between: the frame after the last step is the frame of one long run
+        t.water_init(gx, gy, k, dt, w0, 0, tris[:nw])
+        for _ in range(20):
+            t.water_step(10)
+            last = t.render(**kw)
+        t.water_init(gx, gy, k, dt, w0, 0, tris[:nw])
+        t.water_step(200)
+        once = t.render(**kw)
+        assert np.array_equal(last[1], once[1]) and np.array_equal(last[0].view(np.uint32), once[0].view(np.uint32))
     finally:
         t.close()
 
@@ -1333,9 +1314,9 @@ def test_tree_layout_changes_nothing(default_model, bunny0_model, pool_model):
 
 
 def test_deterministic_mode_decides_nothing_from_measurements(pool_model):
-    """LrlTuning.deterministic = 1: no timed trial of triangle trips, no adaptation of the hand-over thresholds, no refit of a moved scene at
-    rest: every frame of a scene issues the same launches.  Twelve frames in a row report the base thresholds, trialState 0 and triangle
-    trips off, and give the adaptive mode's frame bit for bit; after a water step the caller's boxes stay in use however many frames follow."""
+    """LrlTuning.deterministic = 1: no timed trial of triangle trips, no adaptation of the hand-over thresholds: every frame of a scene
+    issues the same launches.  Twelve frames in a row report the base thresholds, trialState 0 and triangle trips off, and give the
+    adaptive mode's frame bit for bit.  (The refit of a caller's tree after a water step is a fixed sequence of launches in either mode.)"""
     from raytracing_amd import tracer as T
     g = load_golden("pool_viewB_192")
     gx, gy = scenes.POOL_GRID
@@ -1363,9 +1344,10 @@ def test_deterministic_mode_decides_nothing_from_measurements(pool_model):
                 assert infos[0]["handoverTrips"][:4] == [48, 48, 32, 16]
                 t.water_init(gx, gy, k, dt, w0, 0, tris[:nw])
                 t.water_step(100)
-                for i in range(12):                                  # (adaptive mode fits the tree again after a few of these: test_a_moved_scene_is_fitted_again_when_it_pays)
+                for i in range(6):
                     t.render(**kw)
-                    assert t.scene_info()["ownBoxes"] == 0
+                    info = t.last_render_info()
+                    assert info["trialState"] == 0 and info["phasedTrips"] == 0 and info["handoverTrips"] == infos[0]["handoverTrips"], info
             else:
                 assert any(i["trialState"] != 0 for i in infos)
         finally:
