@@ -378,8 +378,16 @@ int lrl_scene_upload(LrlContext* c, const LrlSceneView* s) {
     if (s->cubeSize) for (int i = 0; i < 6; ++i) if (!s->cubeBGR[i]) return fail(c, LRL_ERR_INVALID_ARG, "cube face missing");
     uint32_t depth = 0;
     uint32_t recCount = 1;
+    auto t0 = std::chrono::steady_clock::now();
+    auto lap = [&](const char* what) {      // (LrlTuning.debug: where an upload's time goes)
+        if (!c->tuning.debug) return;
+        const auto t1 = std::chrono::steady_clock::now();
+        std::fprintf(stderr, "lrl: upload: %s %.3f s\n", what, std::chrono::duration<double>(t1 - t0).count());
+        t0 = t1;
+    };
     int rc = deviceBuild ? LRL_OK : validateBVH(c, s, depth, recCount);
     if (rc) return rc;
+    lap("tree validated");
     c->haveScene = false;
     c->deviceBuilt = false;
     c->waterGX = c->waterGY = 0;      // a new scene: lrl_water_init again
@@ -440,6 +448,7 @@ int lrl_scene_upload(LrlContext* c, const LrlSceneView* s) {
             HIP_TRY(c, hipStreamSynchronize(c->stream));
         }
     }
+    lap("triangles");
     if ((rc = upload(c, c->spheres, s->spheres, size_t(g.sphereNum) * sizeof(LrlSphere)))) return rc;
     if ((rc = upload(c, c->circles, s->circles, size_t(g.circleNum) * sizeof(LrlCircle)))) return rc;
     if ((rc = upload(c, c->cylinders, s->cylinders, size_t(g.cylinderNum) * sizeof(LrlCylinder)))) return rc;
@@ -467,6 +476,7 @@ int lrl_scene_upload(LrlContext* c, const LrlSceneView* s) {
         c->cubeSize = s->cubeSize;
     } else if ((rc = ensure(c, c->cube, 4))) return rc;
     HIP_TRY(c, hipStreamSynchronize(c->stream));
+    lap("other primitives, textures");
     if (!deviceBuild) {
         if ((rc = uploadCallerTree(c, s->bvh, s->bvhNodeNum, recCount, depth))) return rc;
         if (c->tuning.debug) std::fprintf(stderr, "lrl: binary nodes %u (depth %u), four-wide tree height %u\n", s->bvhNodeNum, depth, c->node4Depth);
@@ -475,6 +485,7 @@ int lrl_scene_upload(LrlContext* c, const LrlSceneView* s) {
         if (c->tuning.debug) std::fprintf(stderr, "lrl: device-built tree over %llu primitives: %u records, height %u, four-wide height %u\n",
                                                    (unsigned long long)primTotal, recCount, depth, c->node4Depth);
     }
+    lap("tree");
     c->deviceBuilt = deviceBuild;
     c->primTotal = uint32_t(primTotal);
     c->nodeNum = deviceBuild ? uint32_t(2 * primTotal - 1) : s->bvhNodeNum;

@@ -205,6 +205,64 @@ def test_c3_pool_halton_accumulation_vs_oracle(tracer, mode):
         assert tracer.last_render_info()["batch"] == 8
 
 
+def test_c3_at_its_own_size(tracer):
+    """C3 itself, as bench.py times it: the Pool scene, its own camera, 1920 x 1080, 64 Halton samples, RayTraceDepth 8 (the FAST pipeline
+    takes the frame in passes of a few samples each; asserted).  FAST against PARITY over the whole frame (ids tie-adjusted, image), and both
+    against the oracle on an 8-row stripe of that frame at all 64 samples.  Then the frame after lrl_water_step (Pool/Pool.cpp:648-672: the
+    water's triangles move on the device, the caller's four-wide tree is refitted behind the step by lrl_refit_node4): the same checks
+    against the oracle's own water run."""
+    from conftest import assert_ids
+    m = scenes.pool()
+    W, H, spp = 1920, 1080, 64
+    tr = m.camera(H)
+    view = m.scene_view()
+    gx, gy = scenes.POOL_GRID
+    k, dt = scenes.POOL_WATER
+    nw = 2 * (gx - 1) * (gy - 1)
+    tris = m.arrays()["triangles"]
+    w0 = scenes.pool_water_points(m)
+    tracer.scene_upload(view)
+    tracer.set_camera(tr, W, H)
+    tracer.set_decay_origin((0, 0, 0, 1))
+    assert tracer.scene_info()["ownBoxes"] > 2000
+    jit = host.jitter_table(spp)
+    ts = host.sample_trans(tr, jit)
+    ts0 = host.sample_trans(tr, jit[:1])
+    kw = dict(max_depth=8, variant=abi.VARIANT_POOL, jitter=jit)
+    r0 = 600                                           # a stripe across the water, the walls and the steps
+    tracer.water_init(gx, gy, k, dt, w0, 0, tris[:nw])
+    for steps in (0, 40):
+        if steps:
+            tracer.water_step(steps)
+            ot = O.water_sync(O.water_run(w0, gx, gy, k, dt, steps), gx, gy, tris)
+            v = _view_with(m, ot)
+        else:
+            v = view
+        fast, fhits = tracer.render(mode=abi.MODE_FAST, **kw)
+        ri = tracer.last_render_info()
+        assert ri["passes"] > 1 and ri["passes"] * ri["batch"] >= spp, ri
+        par, phits = tracer.render(mode=abi.MODE_PARITY, **kw)
+        assert_ids(fhits, phits, v, ts0, W, H, ("C3 at its own size, FAST vs PARITY", steps))
+        check_image(fast, par, abi.MODE_FAST, ("C3 at its own size, FAST vs PARITY", steps))
+        oimg, ohits, _ = O.render(v, ts, W, H, max_depth=8, variant=abi.VARIANT_POOL, rows=(r0, r0 + 8), threads=16)
+        assert_ids(phits[r0:r0 + 8], ohits, v, ts0, W, H, ("C3 at its own size, PARITY stripe vs oracle", steps), row0=r0)
+        assert_ids(fhits[r0:r0 + 8], ohits, v, ts0, W, H, ("C3 at its own size, FAST stripe vs oracle", steps), row0=r0)
+        check_image(par[r0:r0 + 8], oimg, abi.MODE_PARITY, ("C3 at its own size, PARITY stripe vs oracle", steps))
+        check_image(fast[r0:r0 + 8], oimg, abi.MODE_FAST, ("C3 at its own size, FAST stripe vs oracle", steps))
+        if steps:
+            assert not np.array_equal(fast[r0:r0 + 8], still)      # (the water is in the stripe: the step was seen)
+        still = fast[r0:r0 + 8].copy()
+
+
+def _view_with(model, triangles):
+    """The model's scene view with another triangle array (same count, same BVH: what the Pool does every frame)."""
+    v = model.scene_view()
+    keep = np.ascontiguousarray(triangles, dtype=abi.TRIANGLE)
+    _view_with.keep = keep
+    v.trianglesOrigin = keep.ctypes.data
+    return v
+
+
 def test_interleaved_shards_compose_the_frame(tracer):
     """LrlRenderParams.rowInterleave: N shards of 16-row stripes, each rendered by one call, give the frame bit for bit, with
     primary-hit ids, for shard counts that divide the stripes evenly and that do not, and a frame height that is no multiple of 16;
