@@ -163,7 +163,9 @@ typedef struct LrlTuning {
     uint32_t sparseFrom;         /* first segment traced with four-wave workgroups (5)                                      */
     int32_t  compactFrom;        /* first segment traced from compacted ray lists; 0 never; -1 = by regime                  */
     float    workLow;            /* frontier entries per handed-over ray below which a threshold doubles (12)               */
-    uint32_t pollLag;            /* scenes with transmission: iterations the host polls behind the queue (1..3)             */
+    uint32_t pollLag;            /* scenes with transmission: iterations the host polls behind the queue (1..3) once a pass
+                                  * outlasts the iterations the last pass needed (those are enqueued without looking);
+                                  * 0: look after every iteration, one behind the queue                                    */
     uint32_t traceRef;           /* 1: FAST arithmetic on the reference-order kernel (diagnostic)                           */
     uint32_t batchSlots;         /* spp > 1: samples are traced together up to this many path slots per launch;             */
                                  /*   0 = 2^25, less where the ray state of a pass would pass 8 GiB                         */

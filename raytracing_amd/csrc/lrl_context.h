@@ -108,6 +108,7 @@ struct LrlContext {
                                         // entry point copies the caller's records here, so that its host-to-device copies are plain DMA from pinned memory
                                         // (a copy from pageable memory makes the runtime stage, and may make it allocate, behind the caller's back)
     std::vector<float> workPerRay;      // per iteration: frontier entries per handed-over ray, last feedback
+    uint32_t expectedIters = 0;         // iterations the last pass of a scene with refraction needed (renderWavefront: enqueued without looking)
     uint32_t feedbackTick = 0;          // samples rendered since the thresholds were reset
     uint32_t contIters = 0;             // words of contHost in flight / ready
     std::vector<LrlTrans> transUploaded;   // what transDev holds (per-sample cameras of the last render)

@@ -358,7 +358,7 @@ using namespace lrl_host;
 extern "C" {
 
 int lrl_scene_upload(LrlContext* c, const LrlSceneView* s) {
-    if (c) { c->handoverThr.clear(); c->feedbackTick = 0; c->contIters = 0; c->phasedTrial.state = 0; c->phasedTrial.signature = 0; }      // the hand-over thresholds start again with a new scene (feedback still in flight is the old scene's: dropped)
+    if (c) { c->expectedIters = 0; c->handoverThr.clear(); c->feedbackTick = 0; c->contIters = 0; c->phasedTrial.state = 0; c->phasedTrial.signature = 0; }      // the hand-over thresholds start again with a new scene (feedback still in flight is the old scene's: dropped)
     if (!c || !s) return LRL_ERR_INVALID_ARG;
     HIP_TRY(c, hipSetDevice(c->device));
     if (int rc0 = orderAfterRenders(c)) return rc0;

@@ -210,6 +210,11 @@ static int renderWavefront(LrlContext* c, const LrlRenderParams* p, const KScene
     const bool perKernel = c->timing && (p->flags & LRL_FLAG_TIME_KERNELS);
     const uint32_t pollLag = std::min(3u, std::max(1u, tn.pollLag));
     const bool poll = c->hasTransmission;    // refraction stacks make the number of segments data dependent
+    // ... but hardly from one pass (or frame) to the next: as many iterations as the last pass needed are enqueued without looking, the
+    // host looks once at the end of that stretch, and goes on one iteration at a time only if paths are still alive.  (Looking every
+    // iteration kept the host one iteration ahead at most, and the late iterations of a pass are shorter than a wake-up of the host: the
+    // Pool at 64 samples spent 13 of its 70 ms per frame between kernels.)  tuning.pollLag = 0 looks every iteration, as before.
+    uint32_t& expected = c->expectedIters;
     if (e0) CRUMB_TRY(c, "hipEventRecord(frame start)", hipEventRecord(e0, stream));
     uint32_t iterations = 0, passIndex = 0;
     for (uint32_t s = f.sampleBegin; s < f.sampleEnd; ++passIndex) {
@@ -261,6 +266,7 @@ static int renderWavefront(LrlContext* c, const LrlRenderParams* p, const KScene
         if (poll) std::memset(aliveWords, 0, size_t(bound) * 4);
         CRUMB_TRY(c, "generate", fast ? lrl_fast::wfLaunchGenerate(k, f, wf, stream) : lrl_parity::wfLaunchGenerate(k, f, wf, stream));
         uint32_t iter = 0;
+        const uint32_t stretch = (poll && tn.pollLag != 0) ? std::min(expected, bound) : 0u;
         for (; iter < bound; ++iter) {
 #ifdef LRL_DIAG
             const bool tl = tlPath && *tlPath && iter == tlWanted && s == f.sampleBegin;
@@ -303,7 +309,13 @@ static int renderWavefront(LrlContext* c, const LrlRenderParams* p, const KScene
 #endif
             CRUMB_TRY(c, "shade", fast ? lrl_fast::wfLaunchShade(k, f, wf, iter, pool, stream) : lrl_parity::wfLaunchShade(k, f, wf, iter, pool, stream));
             if (!poll) continue;   // exact bound: nothing to ask the device, the whole frame is enqueued without a host wait
+            if (iter + 1 < stretch) continue;
             CRUMB_TRY(c, "hipEventRecord(iteration)", hipEventRecord(c->evIter[iter & 3], stream));
+            if (iter + 1 == stretch) {
+                CRUMB_TRY(c, "hipEventSynchronize(stretch)", hipEventSynchronize(c->evIter[iter & 3]));
+                if (reinterpret_cast<volatile uint32_t*>(aliveWords)[iter] == 0) { ++iter; break; }
+                continue;
+            }
             if (iter >= pollLag) {      // look at an earlier iteration while this one runs: the pipeline ends pollLag (empty) iterations late
                 CRUMB_TRY(c, "hipEventSynchronize(iteration)", hipEventSynchronize(c->evIter[(iter - pollLag) & 3]));
                 if (reinterpret_cast<volatile uint32_t*>(aliveWords)[iter - pollLag] == 0) { ++iter; break; }
@@ -312,6 +324,11 @@ static int renderWavefront(LrlContext* c, const LrlRenderParams* p, const KScene
         if (poll && iter == bound) {      // the last iteration has not been looked at yet
             CRUMB_TRY(c, "hipEventSynchronize(last iteration)", hipEventSynchronize(c->evIter[(bound - 1) & 3]));
             if (reinterpret_cast<volatile uint32_t*>(aliveWords)[bound - 1] != 0) return fail(c, LRL_ERR_LIMIT, "wavefront pipeline did not finish within its iteration bound");
+        }
+        if (poll) {      // what this pass needed: up to the first iteration that left nothing alive (every word up to it has been seen written)
+            uint32_t need = 0;
+            while (need < iter && reinterpret_cast<volatile uint32_t*>(aliveWords)[need] != 0) ++need;
+            expected = std::min(need + 1, iter);
         }
         if (bsz > 1) CRUMB_TRY(c, "accumulate", fast ? lrl_fast::wfLaunchAccumulate(f, wf, stream) : lrl_parity::wfLaunchAccumulate(f, wf, stream));
         iterations += iter;
