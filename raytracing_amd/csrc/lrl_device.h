@@ -145,6 +145,7 @@ enum { LRL_CTR_PRIMARY = 0, LRL_CTR_REFLECT, LRL_CTR_REFRACT, LRL_CTR_SHADOW, LR
 #define LRL_WF_HASRAY 2u      /* a closest-hit ray of this path was traced in this iteration */
 #define LRL_WF_PENDING 4u     /* shadow rays of the previous segment were traced: add their light now */
 #define LRL_WF_FIRST 8u       /* the segment in flight is the primary ray */
+#define LRL_WF_DECAY 16u      /* the path has come out of a refraction: its decay is in WFrame::decay (else it is the scene's decayOrigin) */
 #define LRL_WF_DEPTH_SHIFT 8  /* 4 bits: depth */
 #define LRL_WF_SP_SHIFT 12    /* 4 bits: refraction stack entries */
 
@@ -164,8 +165,8 @@ struct WFrame {
     float4* ratio;           // ratioNow
     float4* decay;           // decayNow (kept only when a material transmits: otherwise it never leaves decayOrigin)
     float4* hit;             // closest-hit result of the segment in flight: t, primitive bits, aux
-    float4* pendA;           // pending light terms: diffuse colour, texD
-    float4* pendB;           //                      ratio at the hit, u
+    float4* pendA;           // pending light terms: diffuse colour (FAST: times the ratio at the hit), texD
+    float4* pendB;           //                      PARITY: ratio at the hit, u (FAST keeps u in ratio.w)
     uint32_t* flags;
     float4* rayQ;            // 2 float4 per ray: {origin, tmax (-1: closest-hit)} {direction, k (shadow: light factor; set to -1 when occluded)}
     unsigned long long* maskC;

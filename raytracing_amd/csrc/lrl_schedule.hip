@@ -152,7 +152,9 @@ static int renderWavefront(LrlContext* c, const LrlRenderParams* p, const KScene
     if (c->handoverThr.empty()) {
         c->handoverThr.resize(LRL_FEEDBACK_ITERS);
         for (uint32_t i = 0; i < LRL_FEEDBACK_ITERS; ++i) c->handoverThr[i] = baseThr(i);
-        c->swarmGrid.assign(LRL_FEEDBACK_ITERS, contSlots);
+        // (until a feedback pass says how many rays an iteration hands over, and for good in deterministic mode: the kernel strides over the
+        // slots whatever the grid, and dispatching one workgroup per slot costs 82 us a launch on the Pool's 1.5 M slots, most of them idle)
+        c->swarmGrid.assign(LRL_FEEDBACK_ITERS, std::min(contSlots, 1u << 17));
         c->handoverIdle.assign(LRL_FEEDBACK_ITERS, 0);
     }
     const float workLow = tn.workLow;
