@@ -164,11 +164,13 @@ struct WFrame {
     float4* answer;          // xyz accumulated colour, w = v of the pending light terms
     float4* ratio;           // ratioNow
     float4* decay;           // decayNow (kept only when a material transmits: otherwise it never leaves decayOrigin)
-    float4* hit;             // closest-hit result of the segment in flight: t, primitive bits, aux
+    float2* hit;             // closest-hit result of the segment in flight: t, primitive bits
+    float* hitAux;           //   cylinders and cones: which part was hit (written and read for those two kinds only)
+    float* shadow;           // [light][P]: the light factor k of the segment's shadow ray, set to -1 by the trace kernels when it is occluded
     float4* pendA;           // pending light terms: diffuse colour (FAST: times the ratio at the hit), texD
     float4* pendB;           //                      PARITY: ratio at the hit, u (FAST keeps u in ratio.w)
     uint32_t* flags;
-    float4* rayQ;            // 2 float4 per ray: {origin, tmax (-1: closest-hit)} {direction, k (shadow: light factor; set to -1 when occluded)}
+    float4* rayQ;            // 2 float4 per ray: {origin, tmax (-1: closest-hit)} {direction, 0}
     unsigned long long* maskC;
     unsigned long long* maskS;
     float4* refr;            // refraction stack [entry][4][P], NULL when no material transmits
