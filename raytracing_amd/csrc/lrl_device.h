@@ -174,6 +174,7 @@ struct WFrame {
     float4* shadowQ;         // [light][P] shadow rays: {origin, distance to the light}
     unsigned long long* maskC;
     unsigned long long* maskS;
+    unsigned long long* maskL;   // per 64 path slots: which paths are unfinished (the shade kernel's own; flags of the others are not read)
     float4* refr;            // refraction stack [entry][4][P], NULL when no material transmits
     uint2* overflow;         // [trace workgroup][overflowEntries][64]
     uint32_t* alive;         // [iteration]: set to 1 by the shade kernel while any path is unfinished
