@@ -191,7 +191,7 @@ typedef struct LrlTuning {
                                  /*   bit).  Read by lrl_scene_upload, lrl_scene_update_bvh and lrl_scene_rebuild_bvh                                  */
     uint32_t deterministic;      /* 1: the library decides nothing from measurements: no timed trial of triangle trips (off unless  */
                                  /*   phasedTrips = 1), no adaptation of the hand-over thresholds from earlier frames' counters, no   */
-                                 /*   hand-over launches left out, no refit of a moved scene at rest.  Every frame of a scene and     */
+                                 /*   hand-over launches left out.  Every frame of a scene and                                        */
                                  /*   frame shape then issues the same launches, the first like the hundredth (the image is the same  */
                                  /*   bit for bit either way; what is given up is the few per cent the adaptation finds).  0: adaptive */
 } LrlTuning;
@@ -206,7 +206,8 @@ int lrl_set_tuning(LrlContext* ctx, const LrlTuning* tuning);
 
 /* ---- scene (model.dataInit) ---- */
 int lrl_scene_upload(LrlContext* ctx, const LrlSceneView* scene);
-/* Pool: water triangles rewritten every frame; re-runs TrianglePre on [first, first+count). */
+/* Pool: water triangles rewritten every frame; re-runs TrianglePre on [first, first+count), and refits a caller's fitted four-wide
+ * tree to where the triangles are now (on the device, in stream order; LrlSceneInfo.ownBoxes). */
 int lrl_scene_update_triangles(LrlContext* ctx, uint32_t first, uint32_t count, const LrlTriangle* tris);
 /* The same update for callers that cannot allocate (a tight serving loop, a harness that forbids hipMalloc, host code that runs
  * beside a HIP graph capture).  No counterpart in the reference.  Same arguments, same results; it stages the records in a static
@@ -271,7 +272,8 @@ int lrl_timing_end(LrlContext* ctx, double* total_ms, uint32_t* launches);
 /* Rebuild the tree the library built itself (scene uploaded with LrlSceneView.bvh == NULL) from the CURRENT triangles, after
  * lrl_scene_update_triangles or lrl_water_step moved some: the reference has no counterpart (its Pool keeps tall static boxes
  * around the moving water, /root/reference/Pool/Pool.cpp:250-263; SURVEY 8f rank 1 asks for a refit instead; a rebuild of a
- * small scene costs the same and gives tight boxes).  Error when the caller supplied the tree. */
+ * small scene costs the same and gives tight boxes).  Error when the caller supplied the tree: such a tree keeps its topology and is
+ * refitted to the moved triangles by the update calls and lrl_water_step themselves (a kernel per level, in stream order). */
 int lrl_scene_rebuild_bvh(LrlContext* ctx);
 
 /* ---- Pool water simulation (replaces WaterSimulation of /root/reference/Pool/Pool.cpp:46-235 and the
@@ -301,11 +303,11 @@ typedef struct LrlSceneInfo {
     uint32_t materials;      /* distinct Color records                                                                     */
     uint32_t ownBoxes;       /* a caller's tree: triangles that the four-wide tree of the FAST kernels bounds by their own boxes,
                                 more tightly than the caller's tree does (one parked in an inner node, which the reference tests
-                                whenever the ray enters the node; one whose leaf box was made larger than it is).  0 once a
-                                triangle has left the box it had when the tree came (update calls, water steps): then the
-                                caller's boxes alone decide, as the reference's do while the Pool's water moves under its fixed
-                                tree (Pool/Pool.cpp:250-263), until the next lrl_scene_update_bvh or until the rendering since the
-                                move is worth a new fit (2048 paths per node: the library then fits the tree again by itself).   */
+                                whenever the ray enters the node; one whose leaf box was made larger than it is).  The tree follows
+                                its triangles: after update calls and water steps it is refitted on the device, in stream order,
+                                and this is the last refit's count (the call then waits for it).  A triangle that has left the
+                                box the caller's tree gives it is bounded by that box again, as the reference's Pool bounds its
+                                moving water by boxes made tall enough (Pool/Pool.cpp:250-263), and is not counted.          */
     uint32_t wideNodes;      /* four-wide nodes in use: the FAST kernels' tree is stored compactly, in the order the rays walk it (a   */
                              /* node's children side by side, subtree after subtree)                                                  */
     uint32_t leafOrder;      /* 1: the FAST kernels read a copy of the triangles' hot records in the order of that tree's leaves      */
