@@ -146,6 +146,12 @@ struct RayTrace {
         HIP_CHECK(hipMemcpy(rgba.data(), frameDev, px * 16, hipMemcpyDeviceToHost));
         writePFM(path, frameScale.w, frameScale.h, rgba.data());
     }
+    void writeEXRFile(std::string const& path) {                                  // the same float frame as OpenEXR (with alpha)
+        const size_t px = size_t(frameScale.w) * frameScale.h;
+        std::vector<float> rgba(px * 4);
+        HIP_CHECK(hipMemcpy(rgba.data(), frameDev, px * 16, hipMemcpyDeviceToHost));
+        writeEXR(path, frameScale.w, frameScale.h, rgba.data());
+    }
 
     ~RayTrace() {
         if (frameDev) (void)hipFree(frameDev);
@@ -156,11 +162,11 @@ struct RayTrace {
 
 int main(int argc, char** argv) {
     if (argc < 3) {
-        std::fprintf(stderr, "usage: %s <resources dir> <out.bmp> [--pool] [--size W H] [--frames N] [--fast] [--device-bvh] [--water-steps n] [--move] [--ppm f] [--pfm f]\n", argv[0]);
+        std::fprintf(stderr, "usage: %s <resources dir> <out.bmp> [--pool] [--size W H] [--frames N] [--fast] [--device-bvh] [--water-steps n] [--move] [--ppm f] [--pfm f] [--exr f]\n", argv[0]);
         return 2;
     }
     bool pool = false, fast = false, deviceBVH = false, moveSpheres = false;
-    const char *ppm = nullptr, *pfm = nullptr;
+    const char *ppm = nullptr, *pfm = nullptr, *exr = nullptr;
     int W = 720, H = 480, frames = 1;                                             // the reference's window: 720 x 480 (BVH.cpp:799)
     unsigned waterSteps = 0;
     for (int i = 3; i < argc; ++i) {
@@ -170,6 +176,7 @@ int main(int argc, char** argv) {
         else if (!std::strcmp(argv[i], "--move")) moveSpheres = true;
         else if (!std::strcmp(argv[i], "--ppm") && i + 1 < argc) ppm = argv[++i];
         else if (!std::strcmp(argv[i], "--pfm") && i + 1 < argc) pfm = argv[++i];
+        else if (!std::strcmp(argv[i], "--exr") && i + 1 < argc) exr = argv[++i];
         else if (!std::strcmp(argv[i], "--size") && i + 2 < argc) { W = std::atoi(argv[i + 1]); H = std::atoi(argv[i + 2]); i += 2; }
         else if (!std::strcmp(argv[i], "--frames") && i + 1 < argc) frames = std::atoi(argv[++i]);
         else if (!std::strcmp(argv[i], "--water-steps") && i + 1 < argc) waterSteps = unsigned(std::atoi(argv[++i]));
@@ -194,6 +201,7 @@ int main(int argc, char** argv) {
         test.writeBMP(argv[2]);
         if (ppm) test.writePPMFile(ppm);
         if (pfm) test.writePFMFile(pfm);
+        if (exr) test.writeEXRFile(exr);
         std::printf("%s: %d x %d, %d frame(s), decayOrigin (%g, %g, %g, %g)\n", argv[2], W, H, frames, test.decayOriginData.decayOrigin[0],
                     test.decayOriginData.decayOrigin[1], test.decayOriginData.decayOrigin[2], test.decayOriginData.decayOrigin[3]);
     } catch (std::exception const& e) {

@@ -68,6 +68,75 @@ def read_pfm(path):
     return np.frombuffer(rest, dtype="<f4", count=w * h * 3).reshape(h, w, 3).copy()                # rows bottom-up already
 
 
+def read_exr(path):
+    """A reader for what lrl::writeEXR writes and nothing more: OpenEXR 2, single part, scan lines, uncompressed, FLOAT channels
+    (checked, not assumed: magic, version, every header attribute the format requires, the line offset table)."""
+    b = open(path, "rb").read()
+    assert b[:4] == bytes([0x76, 0x2f, 0x31, 0x01]) and struct.unpack_from("<I", b, 4)[0] == 2
+    at, attrs = 8, {}
+    while b[at] != 0:
+        name_end = b.index(b"\0", at); type_end = b.index(b"\0", name_end + 1)
+        size, = struct.unpack_from("<i", b, type_end + 1)
+        attrs[b[at:name_end].decode()] = (b[name_end + 1:type_end].decode(), b[type_end + 5:type_end + 5 + size])
+        at = type_end + 5 + size
+    at += 1
+    for need in ("channels", "compression", "dataWindow", "displayWindow", "lineOrder", "pixelAspectRatio", "screenWindowCenter", "screenWindowWidth"):
+        assert need in attrs, need
+    assert attrs["compression"] == ("compression", b"\0") and attrs["lineOrder"] == ("lineOrder", b"\0")
+    x0, y0, x1, y1 = struct.unpack("<4i", attrs["dataWindow"][1])
+    w, h = x1 - x0 + 1, y1 - y0 + 1
+    ch, c = [], attrs["channels"][1]
+    k = 0
+    while c[k] != 0:
+        e = c.index(b"\0", k)
+        ptype, _lin, xs, ys = struct.unpack_from("<iiii", c, e + 1)
+        assert ptype == 2 and xs == 1 and ys == 1          # FLOAT, full resolution
+        ch.append(c[k:e].decode()); k = e + 17
+    assert ch == sorted(ch) == ["A", "B", "G", "R"]
+    offsets = struct.unpack_from(f"<{h}Q", b, at)
+    img = np.zeros((h, w, 4), dtype=np.float32)
+    for y, off in enumerate(offsets):
+        yy, size = struct.unpack_from("<ii", b, off)
+        assert yy == y0 + y and size == w * 4 * len(ch)
+        line = np.frombuffer(b, dtype="<f4", count=w * len(ch), offset=off + 8).reshape(len(ch), w)
+        for i, name in enumerate(ch):
+            img[h - 1 - y, :, "RGBA".index(name)] = line[i]      # row 0 = bottom, as the tracer's image
+    assert offsets[-1] + 8 + w * 4 * len(ch) == len(b)
+    return img
+
+
+def test_exr_writer_round_trip():
+    """lrl::writeEXR (lrl/Image.hpp; SURVEY 8f rank 4: "PPM/EXR dump"): a float frame with values beyond [0, 1], negative zero, an
+    infinity and a NaN comes back bit for bit through a reader that checks the OpenEXR structure."""
+    W, H = 37, 11
+    rng = np.random.default_rng(5)
+    img = (rng.standard_normal((H, W, 4)) * 3).astype(np.float32)
+    img[0, 0] = (np.float32("inf"), np.float32("-0.0"), np.float32("nan"), 1.0)
+    src = r'''
+#include <lrl/Image.hpp>
+#include <cstdio>
+#include <cstdlib>
+int main(int argc, char** argv) {
+    const int w = std::atoi(argv[1]), h = std::atoi(argv[2]);
+    std::vector<float> px(size_t(w) * h * 4);
+    FILE* f = std::fopen(argv[3], "rb");
+    if (!f || std::fread(px.data(), 4, px.size(), f) != px.size()) return 1;
+    std::fclose(f);
+    lrl::writeEXR(argv[4], w, h, px.data());
+    return 0;
+}
+'''
+    with tempfile.TemporaryDirectory() as td:
+        cpp, exe, raw, out = (os.path.join(td, n) for n in ("w.cpp", "w", "in.raw", "out.exr"))
+        open(cpp, "w").write(src)
+        img.tofile(raw)
+        r = subprocess.run(["g++", "-std=c++17", "-O1", "-I", os.path.join(REPO, "raytracing_amd", "host"), "-o", exe, cpp], capture_output=True, text=True)
+        assert r.returncode == 0, r.stderr
+        assert subprocess.run([exe, str(W), str(H), raw, out]).returncode == 0
+        back = read_exr(out)
+    assert np.array_equal(back.view(np.uint32), img.view(np.uint32))
+
+
 @pytest.mark.gpu
 def test_headless_example_moves_spheres_and_dumps_ppm_pfm():
     """--move: Movement::run before every frame through lrl_scene_update_primitives + lrl_scene_update_bvh (host tree) or
@@ -98,12 +167,13 @@ def test_headless_example_moves_spheres_and_dumps_ppm_pfm():
         tr.close()
     for extra in ([], ["--device-bvh"]):
         with tempfile.TemporaryDirectory() as td:
-            out, ppm, pfm = (os.path.join(td, n) for n in ("f.bmp", "f.ppm", "f.pfm"))
-            r = subprocess.run([EXE, scenes.BVH_RESOURCES, out, "--size", str(W), str(H), "--frames", "3", "--move", "--ppm", ppm, "--pfm", pfm] + extra,
+            out, ppm, pfm, exr = (os.path.join(td, n) for n in ("f.bmp", "f.ppm", "f.pfm", "f.exr"))
+            r = subprocess.run([EXE, scenes.BVH_RESOURCES, out, "--size", str(W), str(H), "--frames", "3", "--move", "--ppm", ppm, "--pfm", pfm, "--exr", exr] + extra,
                                capture_output=True, text=True, timeout=120)
             assert r.returncode == 0, r.stderr + r.stdout
-            img, img_ppm, img_pfm = read_bmp(out), read_ppm(ppm), read_pfm(pfm)
+            img, img_ppm, img_pfm, img_exr = read_bmp(out), read_ppm(ppm), read_pfm(pfm), read_exr(exr)
         assert np.array_equal(img, img_ppm)
+        assert np.array_equal(img_exr[..., :3].view(np.uint32), img_pfm.view(np.uint32)) and np.all(img_exr[..., 3] == 1.0)
         assert np.array_equal(quantised(img_pfm), img)
         assert np.isfinite(img_pfm).mean() > 0.999 and img_pfm.max() > 1.0       # unclamped values survive in the float dump
         d = np.abs(img.astype(np.int16) - want.astype(np.int16))
