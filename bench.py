@@ -87,6 +87,10 @@ def parse_args():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-c5", action="store_true", help="skip the roofline_c5 record of the default run")
     ap.add_argument("--cpu-rows", type=int, default=0, help="rows of the frame the CPU baseline renders (0 = all)")
+    ap.add_argument("--one-rank-rccl", action="store_true",
+                    help="with --gpus 1: a process group of ONE rank on RCCL, and the step the N-rank run takes (render on a side stream, "
+                         "dist.reduce(async_op=True) overlapping the next frame, or all_gather_into_tensor + un-interleave): the measured "
+                         "configuration's own calls, on the one GPU a test has")
     ap.add_argument("--rehearse", action="store_true",
                     help="N > 1 on a one-GPU box (never the measured configuration): every rank on GPU 0, gloo instead of RCCL (which refuses two ranks on one device)")
     return ap.parse_args()
@@ -383,18 +387,25 @@ def main():
         faulthandler.dump_traceback_later(90, exit=True)     # a hang names its line
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
+    dist_on = world > 1 or a.one_rank_rccl
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group(backend="gloo" if rehearse else "nccl", **({} if rehearse else {"device_id": dev}))
+    elif dist_on:
+        import socket
+        with socket.socket() as sk:
+            sk.bind(("127.0.0.1", 0))
+            port = sk.getsockname()[1]
+        dist.init_process_group(backend="nccl", init_method=f"tcp://127.0.0.1:{port}", rank=0, world_size=1, device_id=dev)
 
     ok = True
     try:
-        run(a, torch, dist, sharding, rank, local_rank, world, dev, rehearse)
+        run(a, torch, dist, sharding, rank, local_rank, world, dev, rehearse, dist_on)
     except BaseException:
         ok = False
         import traceback
         traceback.print_exc()
-    if world > 1:
+    if dist_on:
         if ok:
             dist.barrier()
             dist.destroy_process_group()
@@ -404,7 +415,7 @@ def main():
         sys.exit(1)
 
 
-def run(a, torch, dist, sharding, rank, local_rank, world, dev, rehearse):
+def run(a, torch, dist, sharding, rank, local_rank, world, dev, rehearse, dist_on):
     scaling = a.scaling or WORKLOADS[a.workload][8]
     steps = a.steps or {"c1": 50, "c2": 50, "c3": 5, "c4": 3, "c5": 5}[a.workload]
     # (at least eight: three frames settle the hand-over thresholds, four are timed by the library itself to decide on triangle trips)
@@ -413,17 +424,17 @@ def run(a, torch, dist, sharding, rank, local_rank, world, dev, rehearse):
     wl.count()
     W, H = wl.W, wl.H
 
-    stream = torch.cuda.Stream(device=dev) if world > 1 else None
+    stream = torch.cuda.Stream(device=dev) if dist_on else None
     raw = stream.cuda_stream if stream else None
     if scaling == "strong":
         index = sharding.interleave_index(H, world)
         idx_dev, pad = index[0].to(dev), index[1]
         part = torch.zeros((pad, W, 4), dtype=torch.float32, device=dev)
-        gathered = torch.empty((world * pad, W, 4), dtype=torch.float32, device=dev) if world > 1 else part
+        gathered = torch.empty((world * pad, W, 4), dtype=torch.float32, device=dev) if dist_on else part
         frame = [None]
         outs = [part]
     else:
-        outs = [torch.empty((H, W, 4), dtype=torch.float32, device=dev) for _ in range(2 if world > 1 else 1)]
+        outs = [torch.empty((H, W, 4), dtype=torch.float32, device=dev) for _ in range(2 if dist_on else 1)]
     works = [None, None]
     counter = [0]
     # The all-reduce of frame i overlaps the rendering of frame i + 1 (RCCL: stream-level waits only, the host never blocks).  Not in
@@ -432,7 +443,7 @@ def run(a, torch, dist, sharding, rank, local_rank, world, dev, rehearse):
     # call of the render path returns, and a render with nothing of gloo's queued before it finishes on the device; what stops is the
     # render stream's wait on the copy-back event of gloo's DEVICE-tensor all-reduce (its worker thread stages through pinned memory on
     # pool streams of its own), with two processes on one GPU.  RCCL has no such thread and no staging.
-    overlap = world > 1 and scaling == "weak" and not a.no_overlap and not rehearse
+    overlap = dist_on and scaling == "weak" and not a.no_overlap and not rehearse
 
     # the frame is needed in one place (the reference shows it in one window): a reduce to rank 0 moves half the bytes of an all-reduce
     def all_reduce_(t):
@@ -452,7 +463,7 @@ def run(a, torch, dist, sharding, rank, local_rank, world, dev, rehearse):
             dist.all_gather_into_tensor(full, mine)
 
     def step():
-        if world == 1:
+        if not dist_on:
             wl.render_into(outs[0].data_ptr())
             if scaling == "strong":
                 frame[0] = part.index_select(0, idx_dev)          # the same un-interleave the N-rank frame pays
@@ -500,7 +511,7 @@ def run(a, torch, dist, sharding, rank, local_rank, world, dev, rehearse):
             step()
         drain()
         extra += 4
-    if world > 1:
+    if dist_on:
         mx_ex = torch.tensor([extra], dtype=torch.int64, device="cpu" if rehearse else dev)
         dist.all_reduce(mx_ex, op=dist.ReduceOp.MAX)
         for _ in range(int(mx_ex[0]) - extra):
@@ -508,7 +519,7 @@ def run(a, torch, dist, sharding, rank, local_rank, world, dev, rehearse):
         drain()
         extra = int(mx_ex[0])
     settled = wl.tr.last_render_info()["trialState"] != 1
-    if world > 1:
+    if dist_on:
         dist.barrier()
     torch.cuda.synchronize()
     wl.tr.timing_begin()
@@ -516,7 +527,7 @@ def run(a, torch, dist, sharding, rank, local_rank, world, dev, rehearse):
     for _ in range(steps):
         step()
     drain()
-    if world > 1:
+    if dist_on:
         dist.barrier()
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
@@ -529,7 +540,7 @@ def run(a, torch, dist, sharding, rank, local_rank, world, dev, rehearse):
     tot = torch.tensor([elapsed, float(wl.rays)], dtype=torch.float64, device=dev)
     per_rank_ms = [elapsed / steps * 1e3]
     backend = None
-    if world > 1:
+    if dist_on:
         backend = dist.get_backend()
         if rehearse:
             tot = tot.cpu()
@@ -556,7 +567,7 @@ def run(a, torch, dist, sharding, rank, local_rank, world, dev, rehearse):
                                                    "width": W, "height": H, "spp": wl.spp, "depth": wl.depth, "diffuse": wl.diffuse})
     if world == 1 and a.workload == "c5" and not a.tuning and not (a.grid or a.spp or a.depth or a.width or a.builder or a.diffuse):
         traffic, valu, profile = load_traffic("_c5", {"workload_triangles": int(wl.view.num.triangleNum), "spp": wl.spp, "depth": wl.depth})
-    if world > 1:
+    if dist_on:
         # the collective library that actually ran: "nccl" is RCCL on ROCm; the one-GPU rehearsal runs gloo on host copies
         lib_name = {"nccl": "RCCL", "gloo": "gloo (host copies: one-GPU rehearsal, not the measured configuration)"}.get(backend, str(backend))
         par = (f"replicated scene, {wl.spp} sample indices per GPU, {lib_name} reduce of the image onto rank 0" + (" overlapping the next frame" if overlap else "")
@@ -571,7 +582,7 @@ def run(a, torch, dist, sharding, rank, local_rank, world, dev, rehearse):
                    "bvh_wide_depth": wl.info["wideDepth"], "arithmetic": a.mode, "parallelism": par,
                    "rays_per_frame": int(rays_all), "host_scene_build_s": round(wl.build_s, 2), "scene_upload_s": round(wl.upload_s, 2),
                    "device_scene_bytes": wl.tr.scene_device_bytes(),
-                   "collective_backend": backend, "ranks_seen_by_backend": dist.get_world_size() if world > 1 else 1,
+                   "collective_backend": backend, "ranks_seen_by_backend": dist.get_world_size() if dist_on else 1,
                    "ms_per_step_per_rank": [round(x, 4) for x in per_rank_ms],
                    "schedule": dict({k: rinfo[k] for k in ("passes", "batch", "iterations", "compactFrom", "groupLanes", "frontierEntries", "contSlots", "coopFetch", "streamWords", "phasedTrips", "handoverTrips", "trialState")},
                                     settled=bool(settled), extra_warmup_frames=extra, deterministic=int(wl.tr.get_tuning().deterministic))},

@@ -384,3 +384,30 @@ def test_bench_two_rank_loop_rehearsal(scaling):
     assert abs(l2["value"] - r2 / (l2["ms_per_step"] * 1e-3) / 1e6) <= 0.01 * l2["value"]
     # two processes share one GPU and stage their collectives through the host: no speed bar, only sanity against the one-rank rate
     assert 0.02 * l1["value"] <= l2["value"] <= 2.5 * l1["value"], (l1["value"], l2["value"])
+
+
+@pytest.mark.parametrize("scaling", ["weak", "strong"])
+def test_bench_rccl_step_with_one_rank(scaling):
+    """`python bench.py --one-rank-rccl`: the step of the MEASURED multi-GPU configuration with the collective library it is measured
+    with, on the one GPU a test has: a process group of one rank on RCCL (backend "nccl"), renders on a side stream,
+    `dist.reduce(async_op=True)` overlapping the next frame (weak) or `all_gather_into_tensor` + un-interleave (strong), the barriers, the
+    device-side max / sum over ranks.  One rank moves no bytes between GPUs; what this pins is that every RCCL call of the loop is issued
+    with tensors, streams and an order the library accepts, and that the line names the backend that ran.  The frame and the rate must be
+    the plain one-GPU run's (same rays; time within a factor that allows for the extra launches)."""
+    import json
+    import subprocess
+    import sys
+    from conftest import REPO
+    base = [sys.executable, os.path.join(REPO, "bench.py"), "--workload", "c1", "--steps", "4", "--warmup", "2", "--no-cpu-baseline", "--no-c5", "--scaling", scaling]
+    one = subprocess.run(base, capture_output=True, text=True, timeout=300, cwd=REPO)
+    assert one.returncode == 0, one.stderr[-2000:]
+    rccl = subprocess.run(base + ["--one-rank-rccl"], capture_output=True, text=True, timeout=300, cwd=REPO)
+    assert rccl.returncode == 0, rccl.stderr[-3000:]
+    l1 = json.loads([l for l in one.stdout.splitlines() if l.startswith("{")][-1])
+    l2 = json.loads([l for l in rccl.stdout.splitlines() if l.startswith("{")][-1])
+    cfg = l2["config"]
+    assert l2["n_gpus"] == 1 and cfg["collective_backend"] == "nccl" and cfg["ranks_seen_by_backend"] == 1 and "RCCL" in cfg["parallelism"], cfg
+    assert ("overlapping the next frame" in cfg["parallelism"]) == (scaling == "weak")
+    assert cfg["rays_per_frame"] == l1["config"]["rays_per_frame"]
+    assert 0.5 * l1["value"] <= l2["value"] <= 1.5 * l1["value"], (l1["value"], l2["value"])
+
