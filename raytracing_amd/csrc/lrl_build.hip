@@ -848,10 +848,11 @@ __global__ void callerLeafRootKernel(const LrlBVHNode* bvh, OwnBoxes own, float4
 // The topology stays (refs, layout, depth); every node's child boxes are made again, bottom-up, by the rule above (primBox; an inner child:
 // the union of its own items).  src4 = per item the binary node of the caller's tree whose box that is (bit 31: the primitive parked in that node).
 // One launch per level of readiness, as fitLevelKernel: a node is done by the first launch that finds its inner children done earlier.
-__global__ __launch_bounds__(256) void refitLevelKernel(uint4* node4, uint32_t nodes, const uint4* __restrict__ src4, const LrlBVHNode* __restrict__ bvh,
-                                                        OwnBoxes own, float4* boxLo, float4* boxHi, uint32_t* doneAt, uint32_t launch, uint32_t* tight) {
+// (one pass over nodes first, first + stride, ...: -> primitives of the nodes done by it that are bounded more tightly than by the caller's tree)
+DI uint32_t refitPass(uint4* node4, uint32_t nodes, const uint4* __restrict__ src4, const LrlBVHNode* __restrict__ bvh, const OwnBoxes& own, float4* boxLo, float4* boxHi,
+                      uint32_t* doneAt, uint32_t launch, uint32_t first, uint32_t stride) {
     uint32_t fitted = 0;
-    for (uint32_t r = blockIdx.x * 256u + threadIdx.x; r < nodes; r += gridDim.x * 256u) {
+    for (uint32_t r = first; r < nodes; r += stride) {
         if (doneAt[r] != 0u) continue;
         const uint4 q2 = node4[size_t(r) * 4 + 2], q3 = node4[size_t(r) * 4 + 3], s = src4[r];
         const uint32_t refs[4] = {q2.z, q2.w, q3.x, q3.y}, srcs[4] = {s.x, s.y, s.z, s.w};
@@ -882,8 +883,29 @@ __global__ __launch_bounds__(256) void refitLevelKernel(uint4* node4, uint32_t n
         boxLo[r] = make_float4(nlo.x, nlo.y, nlo.z, 0.0f); boxHi[r] = make_float4(nhi.x, nhi.y, nhi.z, 0.0f);
         doneAt[r] = launch;
     }
+    return fitted;
+}
+__global__ __launch_bounds__(256) void refitLevelKernel(uint4* node4, uint32_t nodes, const uint4* __restrict__ src4, const LrlBVHNode* __restrict__ bvh,
+                                                        OwnBoxes own, float4* boxLo, float4* boxHi, uint32_t* doneAt, uint32_t launch, uint32_t* tight) {
+    uint32_t fitted = refitPass(node4, nodes, src4, bvh, own, boxLo, boxHi, doneAt, launch, blockIdx.x * 256u + threadIdx.x, gridDim.x * 256u);
     for (int o = 32; o; o >>= 1) fitted += __shfl_xor(fitted, o);
     if ((threadIdx.x & 63u) == 0u && fitted) atomicAdd(tight, fitted);      // primitives bounded more tightly than by the caller's tree
+}
+// a small tree (the Pool: 3.3 k nodes, refitted after every water step of a one-sample frame): every level in ONE workgroup, a barrier
+// between levels instead of a launch (what a workgroup writes is visible to it after the barrier)
+#define LRL_REFIT_SMALL_NODES 8192u
+__global__ __launch_bounds__(1024) void refitSmallKernel(uint4* node4, uint32_t nodes, const uint4* __restrict__ src4, const LrlBVHNode* __restrict__ bvh,
+                                                         OwnBoxes own, float4* boxLo, float4* boxHi, uint32_t* doneAt, uint32_t levels, uint32_t* tight) {
+    for (uint32_t r = threadIdx.x; r < nodes; r += 1024u) doneAt[r] = 0u;
+    if (threadIdx.x == 0) *tight = 0u;
+    __syncthreads();
+    uint32_t fitted = 0;
+    for (uint32_t launch = 1; launch <= levels; ++launch) {
+        fitted += refitPass(node4, nodes, src4, bvh, own, boxLo, boxHi, doneAt, launch, threadIdx.x, 1024u);
+        __syncthreads();
+    }
+    for (int o = 32; o; o >>= 1) fitted += __shfl_xor(fitted, o);
+    if ((threadIdx.x & 63u) == 0u && fitted) atomicAdd(tight, fitted);
 }
 // triLeaf[posOfTri[i]] = triHot[i], with the triangle's number in the record (the kernels report hits by it)
 __global__ __launch_bounds__(256) void triLeafGatherKernel(const float4* __restrict__ triHot, const uint32_t* __restrict__ posOfTri, uint32_t first, uint32_t count,
@@ -990,6 +1012,11 @@ hipError_t lrl_refit_node4(uint4* node4, uint32_t nodes, const uint4* src4, cons
     float4* boxLo = reinterpret_cast<float4*>(p);
     float4* boxHi = boxLo + nodes;
     uint32_t* doneAt = reinterpret_cast<uint32_t*>(boxHi + nodes);
+    if (nodes <= LRL_REFIT_SMALL_NODES) {
+        hipLaunchKernelGGL(lrl_build::refitSmallKernel, dim3(1), dim3(1024), 0, stream, node4, nodes, src4, bvh, lrl_build::OwnBoxes{pmin, pmax, triCount, pad}, boxLo, boxHi, doneAt,
+                           levels, doneAt + nodes);
+        return hipGetLastError();
+    }
     hipError_t e = hipMemsetAsync(doneAt, 0, size_t(nodes) * 4 + 4, stream);      // (and the count behind them)
     if (e != hipSuccess) return e;
     const dim3 grid(std::min<uint32_t>((nodes + 255u) / 256u, 16384u));
