@@ -12,7 +12,7 @@ the CPU oracle's counts, tests/).
 
 Roofline (two records in the one JSON line):
   roofline     the timed workload.  C1-C4 touch a working set that sits in the 256 MiB Infinity Cache (C2: 199 MB), so no HBM number
-               bounds them.  What does, by the counters (profiles/r02_c2_pmc.json), is VALU issue: `bound` = "valu", `achieved` = wave64
+               bounds them.  What does, by the counters (profiles/r03_c2_pmc.json), is VALU issue: `bound` = "valu", `achieved` = wave64
                VALU instructions of the trace kernels per second (PMC pass SQ_INSTS_VALU of the same kernels on the same workload, a
                count that does not depend on the run, over this run's trace-kernel time: HIP events around every trace launch on the
                stream they run on), `peak` = 1024 SIMDs x 2.4 GHz / 4 cycles per instruction.  Second: `l1_gather` = bytes the timed
@@ -23,10 +23,13 @@ Roofline (two records in the one JSON line):
                without a PMC record of their own (other scenes, --tuning) report `bound` = "l1" with the gather figure.
   roofline_c5  SURVEY 8d's C5, the configuration the memory roofline is judged on (100.5 M triangles, device-built tree, diffuse
                bounces, 16 spp; 22 GB of scene, far beyond the caches): `achieved` = the HBM traffic of the trace kernels (PMC passes of
-               the same kernels on the same workload, profiles/r02_traffic_c5.json) / this run's trace-kernel time against the 8 TB/s
+               the same kernels on the same workload, profiles/r03_traffic_c5.json) / this run's trace-kernel time against the 8 TB/s
                HBM peak; `algorithmic_frac` = SURVEY 8d's algorithmic bytes over the same time (the caches serve part of them, so it
                can pass 1); the HBM line-request rate beside what tools/probes/hbm_gather.hip measured this chip to give such a
-               stream, and valu_issue.  N = 1 default runs only (--no-c5 skips it).
+               stream, and valu_issue; `verified`: that scene's primary hits against a tree-free brute-force oracle on 256 pixels and
+               FAST against PARITY over the frame.  N = 1 default runs only (--no-c5 skips it).
+  Both records name the PMC summary they take their numerator from and say whether it was measured on the sources this library was
+  built from (`profile_matches_build`: the summaries carry a hash of raytracing_amd/csrc); when it was not, `frac` is withheld.
 
 N > 1 (one rank per GPU; `python bench.py --gpus N` starts the ranks itself through torch.distributed.run when it is not already
 under one): the scene is replicated.
@@ -35,7 +38,9 @@ under one): the scene is replicated.
                    overlaps the rendering of the next frame (two image buffers, stream-level waits only).
   --scaling strong (default for c4: ONE 3840x2160 x 256 spp frame of the C2 scene) every rank renders its interleaved 16-row stripes
                    (LrlRenderParams.rowInterleave, one call), one RCCL all-gather per frame inside the timed region + the un-interleave.
-value = rays of all ranks / max-over-ranks time.
+value = rays of all ranks / max-over-ranks time.  The line says which collective library ran and how many ranks it saw.
+  --rehearse       N ranks on GPU 0 with gloo on host copies (RCCL refuses two ranks on one device): the loop, not the library.
+  --one-rank-rccl  with --gpus 1: a process group of one rank on RCCL and the N-rank step: the library's calls, not the traffic.
 """
 import argparse
 import json

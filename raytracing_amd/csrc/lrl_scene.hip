@@ -33,6 +33,10 @@ int validateBVH(LrlContext* c, const LrlSceneView* s, uint32_t& depthOut, uint32
     if (N == 0 || N >= LRL_REF_LEAF) return fail(c, LRL_ERR_INVALID_ARG, "bvhNodeNum out of range");
     const uint32_t counts[7] = {0, 0, s->num.triangleNum, s->num.sphereNum, s->num.circleNum, s->num.cylinderNum, s->num.coneNum};
     uint32_t inner = 0;
+    // (a node with two parents: the device passes give every node ONE place in the packed tree; a shared subtree would leave one of its
+    // parents pointing at a slot nobody writes)
+    std::vector<uint8_t> hasParent(N, 0);
+    auto adopt = [&](uint32_t child) { const bool twice = hasParent[child] != 0; hasParent[child] = 1; return twice; };
     for (uint32_t i = 0; i < N; ++i) {
         const LrlBVHNode& n = s->bvh[i];
         inner += n.bound.leftChild != 0 ? 1u : 0u;
@@ -40,6 +44,9 @@ int validateBVH(LrlContext* c, const LrlSceneView* s, uint32_t& depthOut, uint32
         if (n.bound.rightChild != 0 && (n.bound.rightChild < 0 || uint32_t(n.bound.rightChild) >= N || uint32_t(n.bound.rightChild) <= i))
             return fail(c, LRL_ERR_INVALID_ARG, "BVH: right child index invalid (must be a later pre-order index)");
         if (n.bound.rightChild != 0 && n.bound.leftChild == 0) return fail(c, LRL_ERR_INVALID_ARG, "BVH: right child without left child");
+        if (n.bound.rightChild != 0 && uint32_t(n.bound.rightChild) == i + 1) return fail(c, LRL_ERR_INVALID_ARG, "BVH: left and right child are the same node");
+        if ((n.bound.leftChild != 0 && adopt(i + 1)) || (n.bound.rightChild != 0 && adopt(uint32_t(n.bound.rightChild))))
+            return fail(c, LRL_ERR_INVALID_ARG, "BVH: a node has two parents");
         if (n.axis > 2) return fail(c, LRL_ERR_INVALID_ARG, "BVH: axis > 2");
         if (n.geometry != 0) {
             if (n.geometry < 2 || n.geometry > 6) return fail(c, LRL_ERR_INVALID_ARG, "BVH: unknown geometry type");

@@ -393,6 +393,52 @@ def chain_scene(n):
     return m, v
 
 
+def test_malformed_trees_are_refused(tracer, pool_model):
+    """lrl_scene_upload validates a caller's tree on the host before any kernel indexes with it: a child index out of range or not later
+    in pre-order, a right child without a left one, an unknown primitive class, a primitive number beyond its array, and a node with two
+    parents (the device passes give every node one place in the packed tree) are all refused with LRL_ERR_INVALID_ARG, and the context
+    renders the next valid scene as if nothing had happened."""
+    from raytracing_amd.tracer import TraceError
+    g = load_golden("pool_viewB_192")
+    view = pool_model.scene_view()
+    good = pool_model.arrays()["bvh"]
+    inner = np.flatnonzero((good["leftChild"] != 0) & (good["rightChild"] != 0))
+    leaves = np.flatnonzero((good["leftChild"] == 0) & (good["geometry"] == 2))
+
+    def broken(edit):
+        b = good.copy()
+        edit(b)
+        return b
+
+    def two_parents(b):                                   # two inner nodes name the same right child
+        c = int(inner[40])
+        d = next(int(x) for x in inner if int(x) != c and int(b["rightChild"][x]) > c + 1)
+        b["rightChild"][c] = b["rightChild"][d]
+
+    cases = {
+        "right child past the end": lambda b: b["rightChild"].__setitem__(int(inner[5]), len(b) + 7),
+        "right child not later in pre-order": lambda b: b["rightChild"].__setitem__(int(inner[5]), int(inner[5])),
+        "right child without left": lambda b: (b["leftChild"].__setitem__(int(leaves[9]), 0), b["rightChild"].__setitem__(int(leaves[9]), len(b) - 1)),
+        "left child past the end": lambda b: b["leftChild"].__setitem__(len(b) - 1, 1),
+        "unknown primitive class": lambda b: b["geometry"].__setitem__(int(leaves[3]), 9),
+        "primitive number beyond its array": lambda b: b["geometryNum"].__setitem__(int(leaves[3]), view.num.triangleNum),
+        "two parents": two_parents,
+        "axis": lambda b: b["axis"].__setitem__(int(inner[2]), 3),
+    }
+    for what, edit in cases.items():
+        bad = broken(edit)
+        v = pool_model.scene_view()
+        v.bvh = bad.ctypes.data
+        with pytest.raises(TraceError) as e:
+            tracer.scene_upload(v)
+        assert e.value.code == 1, (what, e.value.code)     # LRL_ERR_INVALID_ARG
+    tracer.scene_upload(view)
+    tracer.set_camera(g["trans"], g["width"], g["height"])
+    tracer.set_decay_origin((0, 0, 0, 1))
+    img, hits = tracer.render(max_depth=8, variant=abi.VARIANT_POOL)
+    assert (hits == g["ids"]).all(axis=-1).mean() >= ID_BAR
+
+
 @pytest.mark.parametrize("n", [60, 92, 140])
 def test_deep_chain_tree(tracer, n):
     """Trees far deeper than the LDS stacks: 61 and 93 levels (the traversal stacks spill to their global overflow, the
