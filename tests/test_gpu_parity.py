@@ -81,6 +81,38 @@ def test_precompute_kernels_bit_exact(tracer, default_model):
         assert np.array_equal(cir[f].view(np.uint32), cir_g[f].view(np.uint32)), f
 
 
+@pytest.mark.parametrize("scene", ["default", "pool"])
+def test_scene_given_as_precomputed_triangles(tracer, default_model, pool_model, scene):
+    """LrlSceneView.trianglesGPU: the caller hands over TrianglePre's OUTPUT (the reference's SSBO 2 as its compute pass leaves it,
+    BVH/shaders/TrianglePreCompute0.cpp:55-80) instead of the origin records.  The frames are the frames of the origin upload bit for bit,
+    in both arithmetic modes; without the corners nothing tells the library where a triangle's own box is, so a caller's tree is walked
+    with the caller's boxes (ownBoxes 0) where the origin upload fits it."""
+    m, gname, variant, depth = ((default_model, "bvh_viewB_256", abi.VARIANT_BVH, 6) if scene == "default" else (pool_model, "pool_viewB_192", abi.VARIANT_POOL, 8))
+    g = load_golden(gname)
+    W, H = 160, 160
+    view = m.scene_view()
+    out = {}
+    tracer.scene_upload(view)
+    fitted = tracer.scene_info()["ownBoxes"]
+    tri_gpu = tracer.read_triangles_gpu(0, view.num.triangleNum)
+    for how in ("origin", "gpu"):
+        v = m.scene_view()
+        if how == "gpu":
+            v.trianglesOrigin = None
+            v.trianglesGPU = tri_gpu.ctypes.data
+        tracer.scene_upload(v)
+        tracer.set_camera(g["trans"], W, H)
+        tracer.set_decay_origin((0, 0, 0, 1))
+        out[how] = (tracer.render(max_depth=depth, variant=variant), tracer.render(max_depth=depth, variant=variant, mode=abi.MODE_FAST), tracer.scene_info()["ownBoxes"])
+        back = tracer.read_triangles_gpu(0, view.num.triangleNum)
+        assert back.tobytes() == tri_gpu.tobytes()
+    assert out["origin"][2] == fitted and out["gpu"][2] == 0
+    for k in (0, 1):
+        assert np.array_equal(out["origin"][k][1], out["gpu"][k][1])
+        assert np.array_equal(out["origin"][k][0].view(np.uint32), out["gpu"][k][0].view(np.uint32))
+    assert (out["gpu"][0][1][..., 0] != 0).mean() > 0.2                       # the scene is in view
+
+
 def test_counters_equal_oracle(tracer, default_model):
     g = load_golden("bvh_viewB_192_depth4")
     tracer.scene_upload(default_model.scene_view())
