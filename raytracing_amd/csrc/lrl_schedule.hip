@@ -148,7 +148,14 @@ static int renderWavefront(LrlContext* c, const LrlRenderParams* p, const KScene
     const bool handoverFits = 2 * contStride + 192 <= LRL_SWARM_CAP;      // else (trees hundreds of levels deep) the lean kernel finishes every ray itself
     const uint32_t sparseFrom = tn.sparseFrom;      // (measured: C2 best with none of its 5, C1 with 8 of its 56, C3 with 4 of its 10)
     const bool adapt = tn.adapt != 0 && !deterministic;
-    auto baseThr = [&](uint32_t i) { return tn.handoverListLen ? tn.handoverList[std::min<uint32_t>(i, tn.handoverListLen - 1)] : i < 2 ? handoverEarly : i == 2 ? (handoverEarly + handoverLate) / 2 : handoverLate; };   // few rays left after the first bounces: the waves are free sooner (C2: a plateau around 48,48,32,16,16)
+    // few rays left after the first bounces: the waves are free sooner (C2: a plateau around 48,48,32,16,16).  Beyond the caches the
+    // descent starts one iteration earlier (96, 64, 48, ...): C5 32.9 -> 32.2 ms, the 100 M-triangle scene with mirror bounces 2.54 -> 2.44
+    // (96, 72, 48: 2.45; 96, 96, 72, 48 as in the caches: the former default; C2 with diffuse bounces loses with anything below 48, 48, 32)
+    auto baseThr = [&](uint32_t i) {
+        if (tn.handoverListLen) return tn.handoverList[std::min<uint32_t>(i, tn.handoverListLen - 1)];
+        if (regime == 2) return i == 0 ? handoverEarly : i == 1 ? (handoverEarly + 2 * handoverLate) / 3 : handoverLate;
+        return i < 2 ? handoverEarly : i == 2 ? (handoverEarly + handoverLate) / 2 : handoverLate;
+    };
     if (c->handoverThr.empty()) {
         c->handoverThr.resize(LRL_FEEDBACK_ITERS);
         for (uint32_t i = 0; i < LRL_FEEDBACK_ITERS; ++i) c->handoverThr[i] = baseThr(i);
