@@ -18,6 +18,9 @@
 // Step 3 has a second form (LrlTuning.deviceBuilder): PLOC, below.
 // Not the reference's tree: images agree with a host-built tree except where two primitives are hit at exactly the same
 // distance (tests/test_gpu_parity.py::test_device_built_bvh*).
+// Also here, because they share the node writer and the level-by-level scheme: the four-wide tree in the order the rays walk it
+// (lrl_layout_node4), a CALLER's tree from its 64-B nodes to the two device layouts with the fit to the triangles' own boxes
+// (lrl_caller_tree), and the refit of such a tree after its triangles moved (lrl_refit_node4).
 #include <hip/hip_runtime.h>
 
 #include <algorithm>

@@ -1,6 +1,7 @@
-// liblrltrace.so — the C ABI of include/lrl_trace.h: the scene.  Validation, the AoS -> device-layout repack (records, the caller's tree and
-// its four-wide compressed form, the fit to the primitives' own boxes, the layout in the order the rays walk it), uploads, updates, the
-// device build, the Pool's water simulation.  Host side only; the kernels live in kernels_parity.hip (TrianglePre, CirclePre, water) and lrl_build.hip.
+// liblrltrace.so — the C ABI of include/lrl_trace.h: the scene.  Validation of a caller's tree, uploads, updates, the Pool's water
+// simulation, and the host side of what lrl_build.hip does on the device: the library's own tree (build, layout), a caller's tree (records,
+// fit to the triangles' own boxes, four-wide collapse, layout, refit after every move).  Host side only; the kernels live in
+// kernels_parity.hip (TrianglePre, CirclePre, water) and lrl_build.hip.
 #include "lrl_context.h"
 
 // ---- lrl_scene_update_triangles_noalloc: its staging area ----
