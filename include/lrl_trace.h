@@ -168,7 +168,7 @@ typedef struct LrlTuning {
                                   * 0: look after every iteration, one behind the queue                                    */
     uint32_t traceRef;           /* 1: FAST arithmetic on the reference-order kernel (diagnostic)                           */
     uint32_t batchSlots;         /* spp > 1: samples are traced together up to this many path slots per launch;             */
-                                 /*   0 = 2^25, less where the ray state of a pass would pass 8 GiB                         */
+                                 /*   0 = 2^26, less where the ray state of a pass would pass 24 GiB; passes equally long   */
     uint32_t coopFetch;          /* 1: the trace kernels fetch a 64-B record with four lanes (same records, same frame bit for bit).  A uniformly */
                                  /*   random gather out of more than ~2 GiB is bound by address translations per lane and gains 2.3x that way    */
                                  /*   (tools/probes/hbm_gather.hip); the rays of the measured scenes are more coherent and lose ~12 %.  0: off   */

@@ -51,14 +51,17 @@ static int renderWavefront(LrlContext* c, const LrlRenderParams* p, const KScene
     // pays the tails of its launches once per batch instead of once per sample
     const uint32_t nSamples = f.sampleEnd - f.sampleBegin;
     // (measured, 1080p: C3 132.9 / 131.4 / 131.2 / 128.2 ms per 64-spp frame with batches of 4 / 8 / 16 / 32 samples, 148.8 with one; C5
-    // 67.6 / 63.1 / 60.3 ms per 16-spp frame with 4 / 8 / 16).  Default: 2^25 path slots per launch, as long as the arena stays within 8 GiB
-    const uint64_t batchSlots = tn.batchSlots ? tn.batchSlots : (1u << 25);
+    // 67.6 / 63.1 / 60.3 ms per 16-spp frame with 4 / 8 / 16).  Default: 2^26 path slots per launch, as long as the arena stays within 24 GiB
+    // of the 288 (round 3, with the samples of a pass side by side: C3 64.3 / 63.8 / 63.3 / 63.0 ms with 6 / 8 / 16 / 64 samples a pass, C4
+    // 742 / 732 / 723 ms with 4 / 8 / 16; LrlTuning.batchSlots caps it for a caller who needs the memory), the passes of a frame equally long
+    const uint64_t batchSlots = tn.batchSlots ? tn.batchSlots : (1u << 26);
     uint32_t batch = uint32_t(std::min<uint64_t>(nSamples, std::max<uint64_t>(1, batchSlots / Ppix64)));
     while (batch > 1 && Ppix64 * batch * (1 + uint64_t(L)) >= (1ull << 31)) --batch;
     if (!tn.batchSlots) {
         const uint64_t perSlot = 16 * 6 + 4 + (1 + uint64_t(L)) * 36 + 64ull * (c->hasTransmission ? p->maxDepth : 0u);
-        while (batch > 1 && Ppix64 * batch * perSlot > (8ull << 30)) --batch;
+        while (batch > 1 && Ppix64 * batch * perSlot > (24ull << 30)) --batch;
     }
+    if (batch > 1) batch = (nSamples + (nSamples + batch - 1) / batch - 1) / ((nSamples + batch - 1) / batch);
     // Trace kernel per iteration.  PARITY and counting renders: wfTraceKernel (the reference's visit order).  FAST: the lean
     // one-lane-per-ray kernel over the four-wide tree, which hands rays that are still going after handoverTrips trips to the
     // lanes-per-ray kernel.
