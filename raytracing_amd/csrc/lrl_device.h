@@ -178,6 +178,8 @@ struct WFrame {
     float4* refr;            // refraction stack [entry][4][P], NULL when no material transmits
     uint2* overflow;         // [trace workgroup][overflowEntries][64]
     uint32_t* alive;         // [iteration]: set to 1 by the shade kernel while any path is unfinished
+    uint32_t zeroWords;      // words from `alive` on (alive, hand-over counts, work counters) that the generate kernel clears for its pass
+    uint32_t zeroListWords;  // the same from `listCount` on (the generate kernel sees the array's start there)
     uint32_t* aliveHost;     // the same words in pinned host memory when the host polls them (scenes with transmission), else NULL
     // hand-over of long chains (lrl_lean.inc -> wfTraceSwarmKernel): a ray still going after `handoverTrips` trips leaves
     // its pending work here and a whole wave finishes it

@@ -271,11 +271,9 @@ static int renderWavefront(LrlContext* c, const LrlRenderParams* p, const KScene
         const bool report = special && !deterministic && c->contIters == 0 && (c->feedbackTick++ < 8 || (c->feedbackTick & 7u) == 0);
         wf.feedbackHost = report ? c->contHostDev : nullptr;
         if (report) std::memset(c->contHost, 0, size_t(LRL_FEEDBACK_ITERS) * 32);
-        // one fill (a size that is no multiple of 16 B costs a second fill kernel): alive, hand-over counts, work counters
-        CRUMB_TRY(c, "hipMemsetAsync(alive, counters)", hipMemsetAsync(wf.alive, 0, special ? size_t(LRL_WF_MAX_ITERATIONS) * 8 + size_t(LRL_FEEDBACK_ITERS) * LRL_WORK_COUNTERS * 128
-                                                                                            : size_t(LRL_WF_MAX_ITERATIONS) * 4, stream));
-        if (special && compactFrom != 0 && bound > compactFrom)
-            CRUMB_TRY(c, "hipMemsetAsync(list counts)", hipMemsetAsync(listCounts, 0, size_t(bound) * LRL_LIST_KINDS * 4, stream));
+        // alive, hand-over counts, work counters and the list counts of compacted iterations: cleared by the generate kernel
+        wf.zeroWords = special ? LRL_WF_MAX_ITERATIONS * 2u + LRL_FEEDBACK_ITERS * LRL_WORK_COUNTERS * 32u : LRL_WF_MAX_ITERATIONS;
+        wf.zeroListWords = (special && compactFrom != 0 && bound > compactFrom) ? bound * LRL_LIST_KINDS : 0u;
         // polled words: the half of the pinned array that pass - 2 used (the host has seen that pass end)
         uint32_t* const aliveWords = c->aliveHost + size_t(passIndex & 1u) * LRL_WF_MAX_ITERATIONS;
         wf.aliveHost = poll ? c->aliveHostDev + size_t(passIndex & 1u) * LRL_WF_MAX_ITERATIONS : nullptr;
