@@ -192,6 +192,39 @@ def test_random_scenes_vs_oracle(tracer, seed, builder):
         check_image(img, oimg, mode, ("random scene", seed, builder))
 
 
+@pytest.mark.parametrize("n", [1, 2, 3, 5])
+def test_tiny_scenes_vs_oracle(tracer, n):
+    """A caller's tree of one node (its root is a leaf: callerLeafRootKernel), of three, of a few: the smallest inputs of the device-side
+    repack / fit / layout, in both modes, against the oracle."""
+    m = host.HostModel()
+    t = np.zeros(n, dtype=abi.TRIANGLE)
+    for i in range(n):
+        x = 3.0 * i - 1.5 * (n - 1)
+        t["p1"][i], t["p2"][i], t["p3"][i] = (x - 1.2, -1.0, 0.2 * i), (x + 1.2, -1.0, 0.2 * i), (x, 1.4, 0.5 + 0.2 * i)
+        t["color"][i] = abi.color(d=(0.9, 0.5 + 0.1 * (i % 3), 0.3)) if i % 2 == 0 else abi.color(r=0.6, d=(0.2, 0.2, 0.6))
+    t["uv2"], t["uv3"] = (1, 0), (0, 1)
+    m.add_triangles(t)
+    L = np.zeros(1, dtype=abi.POINTLIGHT)
+    L["color"], L["p"] = [(200, 200, 200)], [(2, -3, 12)]
+    m.add_point_lights(L)
+    m.data_init("reference")
+    m.camera_look_at(50.0, (1.0, -2.0, 14.0), (0, 0, 0))
+    W, H = 96, 64
+    tr = m.camera(H)
+    v = m.scene_view()
+    tracer.scene_upload(v)
+    tracer.set_camera(tr, W, H)
+    tracer.set_decay_origin((0, 0, 0, 1))
+    oimg, ohits, cn = O.render(v, tr, W, H, max_depth=4, threads=4)
+    assert (ohits[..., 0] != 0).any()                    # the camera does see them
+    for mode in (abi.MODE_PARITY, abi.MODE_FAST):
+        img, hits = tracer.render(max_depth=4, mode=mode)
+        assert np.array_equal(hits, ohits), (n, mode, int((hits != ohits).any(axis=-1).sum()))
+        check_image(img, oimg, mode, ("tiny scene", n))
+        img1, hits1 = tracer.render(max_depth=4, mode=mode, jitter=host.jitter_table(3))      # a batch of samples over the same tree
+        assert np.isfinite(img1).all()
+
+
 def test_textured_triangles_pool_variant_vs_oracle(tracer):
     # texture array on glow / diffuse / reflect / transmit slots, uv beyond 1 (REPEAT), Pool variant (no checker)
     rng = np.random.default_rng(11)
