@@ -29,7 +29,7 @@ __global__ __launch_bounds__(256) void trianglePreKernel(const LrlTriangle* __re
     f3 k2 = (dot3(e1, e1) * e2 - d * e1) / s;
     float4* h = triHot + size_t(first + i) * 4;
     const float4 h0 = make_float4(n.x, n.y, n.z, -dot3(n, p1)), h1 = make_float4(p1.x, p1.y, p1.z, k1.x), h2 = make_float4(k1.y, k1.z, k2.x, k2.y),
-                 h3 = make_float4(k2.z, __uint_as_float(first + i), 0.0f, 0.0f);
+                 h3 = make_float4(k2.z, __uint_as_float(first + i), __uint_as_float(material[i]), 0.0f);
     h[0] = h0; h[1] = h1; h[2] = h2; h[3] = h3;
     if (triLeaf) {
         const uint32_t p = posOfTri[first + i];

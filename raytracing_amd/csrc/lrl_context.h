@@ -118,6 +118,7 @@ struct LrlContext {
     std::vector<uint8_t> handoverIdle;  // per iteration: the last feedback saw no ray reach the threshold (the hand-over launch is left out until the next feedback pass)
     hipEvent_t evIter[4] = {nullptr, nullptr, nullptr, nullptr};
     bool hasTransmission = false;       // some material has t != 0: refraction stacks are needed
+    bool triNeedUV = false;             // some triangle material has a texture or the checker: a hit on a triangle needs its texture coordinates
     uint32_t lastIterations = 0;
     float lastMs = 0;
     bool timed = false;

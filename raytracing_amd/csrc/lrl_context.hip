@@ -39,6 +39,7 @@ void fillKScene(const LrlContext* c, KScene& k) {
     k.triHot = static_cast<const float4*>(c->triHot.p);
     k.triLeaf = static_cast<const float4*>(c->leafOrder ? c->triLeaf.p : c->triHot.p);
     k.triCold = static_cast<const LrlTriCold*>(c->triCold.p);
+    k.triNeedUV = c->triNeedUV ? 1u : 0u;
     k.materials = static_cast<const LrlColor*>(c->materials.p);
     k.spheres = static_cast<const LrlSphere*>(c->spheres.p);
     k.circles = static_cast<const LrlCircle*>(c->circles.p);

@@ -17,7 +17,7 @@
 //             each read their own 64 B from L1) and that, not arithmetic, bounds a one-lane-per-ray traversal: four
 //             children per 64 B halve both the fetches and the chain of dependent trips of a ray.
 //             Laid out by lrl_layout_node4 (lrl_build.hip): reachable nodes only, a node's children side by side, subtree after subtree.
-//   triHot    4 x float4 per triangle (64 B, one half cache line): plane | p1,k1.x | k1.yz,k2.xy | k2.z, triangle number
+//   triHot    4 x float4 per triangle (64 B, one half cache line): plane | p1,k1.x | k1.yz,k2.xy | k2.z, triangle number, material index
 //   triLeaf   the same records in the order of node4's leaves (a leaf node's triangles side by side): what the four-wide kernels read
 //   triCold   32 B per triangle: uv1 uv2 uv3, material index   (read once per accepted hit)
 //   materials 80-B Color records, de-duplicated on upload (a mesh usually has a handful)
@@ -64,6 +64,8 @@ struct KScene {
     const float4* triHot;
     const float4* triLeaf;   // the hot records in the order of node4's leaves (the triangle's number in y of the last quarter); == triHot when the tree is not laid out
     const LrlTriCold* triCold;
+    uint32_t triNeedUV;      // 0: no triangle material has a texture or the checker, so a hit on a triangle needs its normal and its material only:
+                             // both are in the hot record (the wavefront shade kernels then leave the cold one alone: one line per hit instead of two)
     const LrlColor* materials;
     const LrlSphere* spheres;
     const LrlCircle* circles;

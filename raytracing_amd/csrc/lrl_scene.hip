@@ -15,9 +15,12 @@ static __device__ __align__(256) unsigned char scratch[size_t(LRL_NOALLOC_MAX_TR
 namespace lrl_host {
 
 bool transmits(const LrlColor& col) { return !(col.t[0] == 0.0f && col.t[1] == 0.0f && col.t[2] == 0.0f); }   // NaN counts as transmitting
+// the shade kernels read u, v of a hit for texture layers (>= 0) and the checker (-2) only
+bool textured(const LrlColor& col) { return col.texR >= 0 || col.texT >= 0 || col.texD >= 0 || col.texG >= 0 || col.texD == -2 || col.texG == -2; }
 
 uint32_t internMaterial(LrlContext* c, const LrlColor& col) {
     if (transmits(col)) c->hasTransmission = true;
+    if (textured(col)) c->triNeedUV = true;
     ColorKey k;
     std::memcpy(k.w, &col, sizeof(k.w));
     auto it = c->materialIndex.find(k);
@@ -413,6 +416,7 @@ int lrl_scene_upload(LrlContext* c, const LrlSceneView* s) {
     c->materialTable.clear();
     c->materialIndex.clear();
     c->hasTransmission = false;
+    c->triNeedUV = false;
     for (uint32_t i = 0; i < g.sphereNum; ++i) if (transmits(s->spheres[i].color)) c->hasTransmission = true;
     for (uint32_t i = 0; i < g.circleNum; ++i) if (transmits(s->circles[i].color)) c->hasTransmission = true;
     for (uint32_t i = 0; i < g.cylinderNum; ++i) if (transmits(s->cylinders[i].color)) c->hasTransmission = true;
@@ -442,10 +446,11 @@ int lrl_scene_upload(LrlContext* c, const LrlSceneView* s) {
                 hot[size_t(i) * 4 + 1] = make_float4(t.p1[0], t.p1[1], t.p1[2], t.k1[0]);
                 hot[size_t(i) * 4 + 2] = make_float4(t.k1[1], t.k1[2], t.k2[0], t.k2[1]);
                 float id; std::memcpy(&id, &i, 4);
-                hot[size_t(i) * 4 + 3] = make_float4(t.k2[2], id, 0, 0);      // (the triangle's number travels in its hot record)
                 LrlTriCold& q = cold[i];
                 std::memcpy(q.uv1, t.uv1, 8); std::memcpy(q.uv2, t.uv2, 8); std::memcpy(q.uv3, t.uv3, 8);
                 q.material = internMaterial(c, t.color); q._pad = 0;
+                float mat; std::memcpy(&mat, &q.material, 4);
+                hot[size_t(i) * 4 + 3] = make_float4(t.k2[2], id, mat, 0);    // (the triangle's number and its material travel in its hot record)
             }
             rc = upload(c, c->triHot, hot.data(), hot.size() * sizeof(float4));
             if (rc) return rc;

@@ -223,6 +223,33 @@ def test_tiny_scenes_vs_oracle(tracer, n):
         check_image(img, oimg, mode, ("tiny scene", n))
         img1, hits1 = tracer.render(max_depth=4, mode=mode, jitter=host.jitter_table(3))      # a batch of samples over the same tree
         assert np.isfinite(img1).all()
+    if n == 3:
+        # no material of these triangles asks for texture coordinates, so the shade kernels take normal and material from the hot record
+        # alone (KScene::triNeedUV); an update that gives one of them a texture layer must bring the coordinates back
+        rng = np.random.default_rng(5)
+        tex = rng.integers(0, 256, size=(1, 8, 8, 3), dtype=np.uint8)
+        t2 = m.arrays()["triangles"].copy()
+        t2["color"][0] = abi.color(d=(1.0, 1.0, 1.0), texD=0)
+        models = []
+        for tris in (t, t2):
+            mm = host.HostModel()
+            mm.add_triangles(tris)
+            mm.add_point_lights(L)
+            mm.set_tex_raw(tex)
+            mm.data_init("reference")
+            models.append(mm)
+        v0, v2 = models[0].scene_view(), models[1].scene_view()
+        o2, oh2, _ = O.render(v2, tr, W, H, max_depth=4, threads=4)
+        assert not np.array_equal(o2, oimg)
+        tracer.scene_upload(v0)                           # the untextured triangles in a scene that has a texture layer
+        tracer.set_decay_origin((0, 0, 0, 1))
+        for tris, want, what in ((None, oimg, "untextured"), (t2, o2, "textured by an update"), (t, oimg, "untextured again"), (t2, o2, "textured again")):
+            if tris is not None:
+                tracer.update_triangles(0, tris)
+            for mode in (abi.MODE_PARITY, abi.MODE_FAST):
+                img, hits = tracer.render(max_depth=4, mode=mode)
+                assert np.array_equal(hits, ohits)
+                check_image(img, want, mode, ("tiny scene", what))
 
 
 def test_textured_triangles_pool_variant_vs_oracle(tracer):
