@@ -172,7 +172,8 @@ struct WFrame {
     float4* pendA;           // pending light terms: diffuse colour (FAST: times the ratio at the hit), texD
     float4* pendB;           //                      PARITY: ratio at the hit, u (FAST keeps u in ratio.w)
     uint32_t* flags;
-    float4* rayQ;            // closest-hit rays, 2 float4 each: {origin, -1} {direction, 0}
+    float4* rayQ;            // closest-hit rays, 24 B each in two arrays: {origin, direction.x} here,
+    float2* rayD;            //   {direction.y, direction.z} here (a closest-hit ray starts with t = -1: nothing to store)
     float4* shadowQ;         // [light][P] shadow rays: {origin, distance to the light}
     unsigned long long* maskC;
     unsigned long long* maskS;

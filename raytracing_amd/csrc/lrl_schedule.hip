@@ -19,14 +19,14 @@ namespace lrl_host {
 // where the blocks of one pass (bsz samples of Ppix path slots each) sit in the arena; every size grows with bsz, so the layout of a
 // smaller last batch fits the arena of a full one
 struct WfLayout {
-    size_t state, flags, shadow, rayQ, shadowQ, maskC, maskS, maskL, refr, ovf, alive, contHead, contRefs, rayList, listCount, total;
+    size_t state, flags, shadow, rayQ, rayD, shadowQ, maskC, maskS, maskL, refr, ovf, alive, contHead, contRefs, rayList, listCount, total;
 };
 static WfLayout wfLayout(size_t P, uint32_t L, uint32_t refrEntries, uint32_t ovfN, uint32_t contSlots, uint32_t contStride, bool special) {
     WfLayout o{};
     size_t off = 0;
     auto take = [&](size_t bytes) { size_t at = off; off += (bytes + 255) / 256 * 256; return at; };
     const size_t words = P / 64, chunks = words * (1 + size_t(L)) / LRL_WF_CHUNK_WORDS;
-    o.state = take(P * 16 * 6); o.flags = take(P * 4); o.shadow = take(P * size_t(L) * 4); o.rayQ = take(P * 32); o.shadowQ = take(P * size_t(L) * 16);
+    o.state = take(P * 16 * 6); o.flags = take(P * 4); o.shadow = take(P * size_t(L) * 4); o.rayQ = take(P * 16); o.rayD = take(P * 8); o.shadowQ = take(P * size_t(L) * 16);
     o.maskC = take(words * 8); o.maskS = take(words * 8); o.maskL = take(words * 8);
     o.refr = take(P * 64 * refrEntries); o.ovf = take(chunks * ovfN * 512);
     o.alive = take(LRL_WF_MAX_ITERATIONS * 4 * 2 + LRL_FEEDBACK_ITERS * LRL_WORK_COUNTERS * 128);
@@ -244,6 +244,7 @@ static int renderWavefront(LrlContext* c, const LrlRenderParams* p, const KScene
         wf.pendA = st + 4 * P; wf.pendB = st + 5 * P;
         wf.flags = reinterpret_cast<uint32_t*>(base + lay.flags);
         wf.rayQ = reinterpret_cast<float4*>(base + lay.rayQ);
+        wf.rayD = reinterpret_cast<float2*>(base + lay.rayD);
         wf.shadowQ = reinterpret_cast<float4*>(base + lay.shadowQ);
         wf.maskC = reinterpret_cast<unsigned long long*>(base + lay.maskC);
         wf.maskS = reinterpret_cast<unsigned long long*>(base + lay.maskS);
