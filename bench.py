@@ -293,7 +293,7 @@ class Workload:
     def roofline(self, kernel_ms, launches, frame_ms, traffic, valu=None, profile=None):
         resident = self.working_set() <= INFINITY_CACHE_BYTES
         stale = profile is not None and not profile["profile_matches_build"]
-        r = {"kernel": ("trace kernels of one frame (wfTraceLeanKernel + the hand-over kernel: wfTraceGroupKernel, or wfTraceSwarmKernel beyond the caches)" if self.mode_name == "fast"
+        r = {"kernel": ("trace kernels of one frame (wfTraceLeanKernel + the hand-over kernel: wfTraceGroupKernel, or wfTraceSwarmKernel beyond the caches; where a material transmits also wfTailKernel, the launch that finishes a pass from its sixth segment on and shades as well)" if self.mode_name == "fast"
                         else "trace kernels of one frame (wfTraceKernel)"),
              "kernel_ms": round(kernel_ms, 4), "launches_per_frame": launches, "frame_ms": round(frame_ms, 4),
              "working_set_bytes": self.working_set(), "traffic": traffic,

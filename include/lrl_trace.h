@@ -148,6 +148,7 @@ typedef struct LrlCounters {
  * adaptive thresholds).  The library reads no environment variable on the render path. */
 #define LRL_TUNING_LIST_MAX 8u
 #define LRL_HANDOVER_AUTO 0xffffffffu
+#define LRL_TAIL_NEVER 0xffffffffu
 typedef struct LrlTuning {
     uint32_t handoverEarly;      /* lean kernel: trips after which a ray still going is handed to the lanes-per-ray kernel, */
     uint32_t handoverLate;       /*   first two segments / later segments; 0 = never hand over; LRL_HANDOVER_AUTO (default) = */
@@ -194,6 +195,10 @@ typedef struct LrlTuning {
                                  /*   hand-over launches left out.  Every frame of a scene and                                        */
                                  /*   frame shape then issues the same launches, the first like the hundredth (the image is the same  */
                                  /*   bit for bit either way; what is given up is the few per cent the adaptation finds).  0: adaptive */
+    uint32_t tailFrom;           /* from this iteration (ray segment) on the rest of a pass is ONE launch in which every workgroup    */
+                                 /*   traces and shades its own 64 path slots until they are finished (same frame bit for bit; pays    */
+                                 /*   where tens of late iterations carry a few hundred paths: C1 2.11 -> 1.24 ms).  0 = 5 for a scene  */
+                                 /*   in which a material transmits, never otherwise; LRL_TAIL_NEVER = never                           */
 } LrlTuning;
 
 /* ---- life cycle ---- */

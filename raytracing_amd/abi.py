@@ -66,7 +66,7 @@ class Tuning(C.Structure):
     _fields_ = [("handoverEarly", C.c_uint32), ("handoverLate", C.c_uint32), ("handoverListLen", C.c_uint32), ("handoverList", C.c_uint32 * 8),
                 ("adapt", C.c_uint32), ("groupLanes", C.c_uint32), ("contSlots", C.c_uint32), ("groupCapX", C.c_uint32), ("sparseFrom", C.c_uint32),
                 ("compactFrom", C.c_int32), ("workLow", C.c_float), ("pollLag", C.c_uint32), ("traceRef", C.c_uint32), ("batchSlots", C.c_uint32),
-                ("coopFetch", C.c_uint32), ("groupQuad", C.c_uint32), ("streamWords", C.c_uint32), ("refillMin", C.c_uint32), ("phasedTrips", C.c_uint32), ("deviceBuilder", C.c_uint32), ("debug", C.c_uint32), ("treeLayout", C.c_uint32), ("deterministic", C.c_uint32)]
+                ("coopFetch", C.c_uint32), ("groupQuad", C.c_uint32), ("streamWords", C.c_uint32), ("refillMin", C.c_uint32), ("phasedTrips", C.c_uint32), ("deviceBuilder", C.c_uint32), ("debug", C.c_uint32), ("treeLayout", C.c_uint32), ("deterministic", C.c_uint32), ("tailFrom", C.c_uint32)]
 
 
 class SceneInfo(C.Structure):

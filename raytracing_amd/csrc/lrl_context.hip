@@ -59,6 +59,7 @@ LrlTuning defaultTuning() {
     t.handoverEarly = LRL_HANDOVER_AUTO; t.handoverLate = LRL_HANDOVER_AUTO; t.handoverListLen = 0;
     t.adapt = 1; t.groupLanes = 0; t.contSlots = 0; t.groupCapX = 0; t.sparseFrom = 5; t.compactFrom = -1; t.coopFetch = 0; t.groupQuad = 0; t.streamWords = 0; t.refillMin = 16; t.phasedTrips = 0; t.deviceBuilder = 0;
     t.workLow = 12.0f; t.pollLag = 1; t.traceRef = 0; t.batchSlots = 0; t.debug = 0; t.treeLayout = 0; t.deterministic = 0;
+    t.tailFrom = 0;
     return t;
 }
 

@@ -213,6 +213,7 @@ LRL_WF_DECLARE(lrl_parity)
 LRL_WF_DECLARE(lrl_fast)
 namespace lrl_fast {
 hipError_t wfLaunchTraceLean(const KScene& sc, const WFrame& wf, bool sparse, bool compact, bool coop, bool phased, uint32_t streamWords, uint32_t refillMin, hipStream_t stream);   // phased: one block a trip   // sparse: few rays in many words (larger workgroups)
+hipError_t wfLaunchTail(const KScene& sc, const KFrame& fr, const WFrame& wf, uint32_t iterFirst, uint32_t iterBound, bool pool, hipStream_t stream);   // the rest of a pass in one launch (lrl_lean.inc)
 hipError_t wfLaunchTraceSwarm(const KScene& sc, const WFrame& wf, uint32_t waves, uint32_t group, bool coop, bool quad, hipStream_t stream);   // coop: four lanes to a record fetch (lrl_lean.inc)
 }
 

@@ -222,6 +222,9 @@ static int renderWavefront(LrlContext* c, const LrlRenderParams* p, const KScene
     const bool perKernel = c->timing && (p->flags & LRL_FLAG_TIME_KERNELS);
     const uint32_t pollLag = std::min(3u, std::max(1u, tn.pollLag));
     const bool poll = c->hasTransmission;    // refraction stacks make the number of segments data dependent
+    // the rest of a pass in one launch (lrl_lean.inc, wfTailKernel): by default where a material transmits, from the sixth segment on
+    const uint32_t tailFrom = tn.tailFrom ? tn.tailFrom : (poll ? 5u : LRL_TAIL_NEVER);
+    const bool useTail = special && tailFrom != LRL_TAIL_NEVER && !ctr;
     // ... but hardly from one pass (or frame) to the next: as many iterations as the last pass needed are enqueued without looking, the
     // host looks once at the end of that stretch, and goes on one iteration at a time only if paths are still alive.  (Looking every
     // iteration kept the host one iteration ahead at most, and the late iterations of a pass are shorter than a wake-up of the host: the
@@ -282,6 +285,8 @@ static int renderWavefront(LrlContext* c, const LrlRenderParams* p, const KScene
         CRUMB_TRY(c, "generate", fast ? lrl_fast::wfLaunchGenerate(k, f, wf, stream) : lrl_parity::wfLaunchGenerate(k, f, wf, stream));
         uint32_t iter = 0;
         const uint32_t stretch = (poll && tn.pollLag != 0) ? std::min(expected, bound) : 0u;
+        bool tailDone = false;
+        uint32_t tailStart = bound;
         for (; iter < bound; ++iter) {
 #ifdef LRL_DIAG
             const bool tl = tlPath && *tlPath && iter == tlWanted && s == f.sampleBegin;
@@ -297,6 +302,21 @@ static int renderWavefront(LrlContext* c, const LrlRenderParams* p, const KScene
                 ta = c->timingEvents[c->timingUsed].first; tb = c->timingEvents[c->timingUsed].second;
                 ++c->timingUsed;
                 HIP_TRY(c, hipEventRecord(ta, stream));
+            }
+            if (useTail && iter >= tailFrom) {
+                tailStart = iter;
+                // the rest of the pass in one launch (wfTailKernel): every wave finishes its own paths; then one look at the words it left
+                CRUMB_TRY(c, "tail", lrl_fast::wfLaunchTail(k, f, wf, iter, bound, pool, stream));
+                if (tb) HIP_TRY(c, hipEventRecord(tb, stream));      // (timed like a trace launch; it shades too)
+                tailDone = true;
+                if (!poll) { iter = bound; break; }      // an exact bound: nothing to ask the device
+                CRUMB_TRY(c, "hipEventRecord(tail)", hipEventRecord(c->evIter[0], stream));
+                CRUMB_TRY(c, "hipEventSynchronize(tail)", hipEventSynchronize(c->evIter[0]));
+                uint32_t last = iter;
+                while (last < bound && reinterpret_cast<volatile uint32_t*>(aliveWords)[last] != 0) ++last;
+                if (last == bound) return fail(c, LRL_ERR_LIMIT, "wavefront pipeline did not finish within its iteration bound");
+                iter = last + 1;
+                break;
             }
             if (special) {
                 const uint32_t fi = std::min(iter, LRL_FEEDBACK_ITERS - 1);
@@ -336,7 +356,7 @@ static int renderWavefront(LrlContext* c, const LrlRenderParams* p, const KScene
                 if (reinterpret_cast<volatile uint32_t*>(aliveWords)[iter - pollLag] == 0) { ++iter; break; }
             }
         }
-        if (poll && iter == bound) {      // the last iteration has not been looked at yet
+        if (poll && iter == bound && !tailDone) {      // the last iteration has not been looked at yet
             CRUMB_TRY(c, "hipEventSynchronize(last iteration)", hipEventSynchronize(c->evIter[(bound - 1) & 3]));
             if (reinterpret_cast<volatile uint32_t*>(aliveWords)[bound - 1] != 0) return fail(c, LRL_ERR_LIMIT, "wavefront pipeline did not finish within its iteration bound");
         }
@@ -348,7 +368,7 @@ static int renderWavefront(LrlContext* c, const LrlRenderParams* p, const KScene
         if (bsz > 1) CRUMB_TRY(c, "accumulate", fast ? lrl_fast::wfLaunchAccumulate(f, wf, stream) : lrl_parity::wfLaunchAccumulate(f, wf, stream));
         iterations += iter;
         if (report) {
-            c->contIters = std::min(iter, LRL_FEEDBACK_ITERS);
+            c->contIters = std::min(std::min(iter, tailStart), LRL_FEEDBACK_ITERS);      // (the tail launch hands nothing over and reports nothing)
             c->contSlotsInFlight = contSlots;
             CRUMB_TRY(c, "hipEventRecord(feedback)", hipEventRecord(c->evCont, stream));
         }

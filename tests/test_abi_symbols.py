@@ -40,7 +40,7 @@ def test_ctypes_mirrors_have_the_headers_layout(tmp_path):
 
     from raytracing_amd import abi
     pairs = [("LrlGeometryNum", abi.GeometryNum, "_pad"), ("LrlSceneView", abi.SceneView, "cubeBGR"), ("LrlRenderParams", abi.RenderParams, "rowShard"),
-             ("LrlTuning", abi.Tuning, "deterministic"), ("LrlSceneInfo", abi.SceneInfo, "leafOrder"), ("LrlRenderInfo", abi.RenderInfo, "trialState"),
+             ("LrlTuning", abi.Tuning, "tailFrom"), ("LrlSceneInfo", abi.SceneInfo, "leafOrder"), ("LrlRenderInfo", abi.RenderInfo, "trialState"),
              ("LrlCounters", abi.Counters, "groupRounds")]
     src = tmp_path / "layout.c"
     src.write_text('#include <stdio.h>\n#include <stddef.h>\n#include "lrl_trace.h"\nint main(void) {\n' +

@@ -593,6 +593,36 @@ def test_compacted_ray_lists_change_nothing(tracer, default_model, bunny0_model)
         tracer.set_tuning(base)
 
 
+def test_the_tail_of_a_pass_in_one_launch_changes_nothing(tracer, default_model, bunny0_model, pool_model):
+    """LrlTuning.tailFrom: from that iteration on one launch finishes the pass, every workgroup tracing and shading its own 64 path slots
+    (wfTailKernel; on by default from the sixth segment where a material transmits).  The same bodies run in the same order per path:
+    the frames with the tail starting anywhere, and without it, are the same bit for bit -- glass in glass (the default scene, depth 10),
+    the Pool's water with a batch of samples, a scene without transmission (exact bound: no look at the device), diffuse bounces."""
+    TAIL_NEVER = 0xffffffff
+    base = tracer.get_tuning()
+    try:
+        for m, (W, H), variant, depth, spp, diffuse in ((default_model, (200, 160), abi.VARIANT_BVH, 10, 1, False),
+                                                        (pool_model, (192, 108), abi.VARIANT_POOL, 8, 4, False),
+                                                        (bunny0_model, (320, 180), abi.VARIANT_BVH, 4, 1, False),
+                                                        (default_model, (160, 120), abi.VARIANT_BVH, 6, 2, True)):
+            tr = m.camera(H)
+            tracer.scene_upload(m.scene_view())
+            tracer.set_camera(tr, W, H)
+            tracer.set_decay_origin((0, 0, 0, 1))
+            jit = host.jitter_table(spp) if spp > 1 else None
+            frames = {}
+            for start in (TAIL_NEVER, 0, 1, 2, 5):
+                tracer.set_tuning(tailFrom=start)
+                frames[start] = tracer.render(max_depth=depth, variant=variant, mode=abi.MODE_FAST, jitter=jit, diffuse=diffuse)
+                again = tracer.render(max_depth=depth, variant=variant, mode=abi.MODE_FAST, jitter=jit, diffuse=diffuse)      # (the second frame: after the feedback of the first)
+                assert np.array_equal(again[0], frames[start][0]), (W, start)
+            for start in (0, 1, 2, 5):
+                assert np.array_equal(frames[start][0], frames[TAIL_NEVER][0]), (W, H, start)
+                assert np.array_equal(frames[start][1], frames[TAIL_NEVER][1]), (W, H, start)
+    finally:
+        tracer.set_tuning(base)
+
+
 def test_cooperative_record_fetches_change_nothing(tracer, default_model, bunny0_model, pool_model):
     """LrlTuning.coopFetch: the FAST trace kernels fetch a 64-B record with four lanes (lanes l, l+16, l+32, l+48 read its four parts,
     a transpose of v_permlane swaps brings them home; a remedy for gathers bound by address translation, off by default).  The record a

@@ -1,19 +1,22 @@
 """A/B of two builds of the library, frame by frame: renders a few FAST frames (default scene with its glass, the Pool with sample batches, a bunny with
 diffuse bounces, a sharded frame) and writes them to an .npz; run once per library (env LRLTRACE_LIB picks it), then `cmp` mode compares.
-usage: ab_frames.py dump out.npz | ab_frames.py cmp a.npz b.npz"""
+usage: ab_frames.py dump out.npz [tuning=value,...] | ab_frames.py cmp a.npz b.npz"""
 import sys, os
 root = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, root)
 import numpy as np
 
 
-def dump(path):
+def dump(path, tuning=""):
     import torch
+    tune = {k: (float(v) if "." in v else int(v)) for k, v in (kv.split("=") for kv in tuning.split(",") if kv)}
     from raytracing_amd import scenes, abi, host, tracer as T
     out = {}
 
     def frames(name, m, W, H, spp, depth, variant, diffuse=False, rows=None):
         t = T.Tracer(0)
+        if tune:
+            t.set_tuning(**tune)
         t.scene_upload(m.scene_view()); t.set_camera(m.camera(H), W, H); t.set_decay_origin((0, 0, 0, 1))
         buf = torch.zeros((H, W, 4), dtype=torch.float32, device="cuda:0")
         for i in range(3):      # (the schedule adapts over the first frames; the image must not)
@@ -45,4 +48,4 @@ def cmp(a, b):
 
 
 if __name__ == "__main__":
-    dump(sys.argv[2]) if sys.argv[1] == "dump" else cmp(sys.argv[2], sys.argv[3])
+    dump(sys.argv[2], sys.argv[3] if len(sys.argv) > 3 else "") if sys.argv[1] == "dump" else cmp(sys.argv[2], sys.argv[3])
